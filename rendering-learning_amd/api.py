@@ -1,0 +1,454 @@
+"""ctypes bindings over the two in-tree native libraries of the product:
+
+  csrc/librl_render.so  — the C-ABI drop-in boundary (include/rl_render.h): HIP kernels for gfx950.
+  host/librl_host.so    — the C++ host mirror of the reference's scene-building API
+                          (CameraParams/Camera::new, Sphere/Bvh/..., World, OBJ loaders, PPM writers).
+
+Python here is plumbing only (tests, bench.py, torch.distributed): no arithmetic of the hot path
+lives in this file, and there is NO CPU fallback — if librl_render.so is missing or no GPU is
+present, every render call raises.
+
+Class / function names mirror the reference:
+  CameraParams, Camera(params).render(world) -> Canvas, render_from_checkpoint, Canvas.merge,
+  output_ppm            <- ray-tracing-one-weekend/src/{camera.rs:23-143,263-296, output.rs:5}
+  RtcCamera.render(world, aa) -> ppm via canvas_ppm
+                        <- ray-tracer-challenge/src/scene/camera.rs:93, draw/canvas.rs:50
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RENDER_LIB = os.path.join(_HERE, "csrc", "librl_render.so")
+HOST_LIB = os.path.join(_HERE, "host", "librl_host.so")
+
+RL_OK, RL_E_INVALID, RL_E_NO_DEVICE, RL_E_DEVICE, RL_E_UNSUPPORTED, RL_E_DEGENERATE, RL_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class RLError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rl error {code}: {msg}")
+        self.code = code
+
+
+# ----------------------------------------------------------------------------- C structs
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("planar_tests", C.c_uint64), ("instance_enters", C.c_uint64), ("rng_words", C.c_uint64),
+                ("flagged", C.c_uint64), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RtiowCamera(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32),
+                ("samples_per_pixel", C.c_uint32), ("max_depth", C.c_uint32),
+                ("lookfrom", C.c_double * 3), ("pixel_00", C.c_double * 3),
+                ("pixel_du", C.c_double * 3), ("pixel_dv", C.c_double * 3),
+                ("defocus_disk_u", C.c_double * 3), ("defocus_disk_v", C.c_double * 3),
+                ("defocus_angle", C.c_double), ("background", C.c_double * 3), ("seed", C.c_uint64)]
+
+
+class RtcCamera(C.Structure):
+    _fields_ = [("hsize", C.c_uint32), ("vsize", C.c_uint32), ("inverse", C.c_double * 16),
+                ("pixel_size", C.c_double), ("half_width", C.c_double), ("half_height", C.c_double)]
+
+
+class _HCameraParams(C.Structure):
+    _fields_ = [("aspect_ratio", C.c_double), ("image_width", C.c_uint64), ("samples_per_pixel", C.c_uint64),
+                ("max_depth", C.c_uint64), ("vfov", C.c_double), ("lookfrom", C.c_double * 3),
+                ("lookat", C.c_double * 3), ("vup", C.c_double * 3), ("defocus_angle", C.c_double),
+                ("focus_dist", C.c_double), ("background", C.c_double * 3), ("seed", C.c_uint64)]
+
+
+# numpy dtypes of the POD scene records (include/rl_render.h) for Python-built scenes
+HREF = np.dtype([("kind", "<u4"), ("index", "<u4")])
+SPHERE = np.dtype([("center0", "<f8", 3), ("center1", "<f8", 3), ("radius", "<f8"), ("moving", "<u4"), ("material", "<u4")])
+MATERIAL = np.dtype([("kind", "<u4"), ("texture", "<u4"), ("albedo", "<f8", 3), ("fuzz", "<f8"), ("ior", "<f8")])
+TEXTURE = np.dtype([("kind", "<u4"), ("even", "<u4"), ("odd", "<u4"), ("image", "<u4"), ("color", "<f8", 3), ("inv_scale", "<f8")])
+RTC_TRIANGLE = np.dtype([("p1", "<f8", 3), ("e1", "<f8", 3), ("e2", "<f8", 3), ("smooth", "<u4"), ("material", "<u4"),
+                         ("n1", "<f8", 3), ("n2", "<f8", 3), ("n3", "<f8", 3)])
+RTC_GROUP = np.dtype([("first", "<u4"), ("count", "<u4")])
+RTC_BOUNDED = np.dtype([("minimum", "<f8", 3), ("maximum", "<f8", 3), ("child", HREF)])
+RTC_TRANSFORMED = np.dtype([("inverse", "<f8", 16), ("inverse_transpose", "<f8", 16), ("child", HREF)])
+RTC_MATERIAL = np.dtype([("color", "<f8", 3), ("ambient", "<f8"), ("diffuse", "<f8"), ("specular", "<f8"), ("shininess", "<f8"),
+                         ("reflectivity", "<f8"), ("transparency", "<f8"), ("refractive_index", "<f8")])
+RTC_LIGHT = np.dtype([("position", "<f8", 3), ("intensity", "<f8", 3)])
+
+MAT_FLAT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3, 4
+TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
+O_TRIANGLE, O_GROUP, O_BOUNDED, O_TRANSFORMED = 1, 2, 3, 4
+
+
+class RtcSceneDesc(C.Structure):
+    _fields_ = [("triangles", C.c_void_p), ("n_triangles", C.c_uint32),
+                ("groups", C.c_void_p), ("n_groups", C.c_uint32),
+                ("group_items", C.c_void_p), ("n_group_items", C.c_uint32),
+                ("boundeds", C.c_void_p), ("n_boundeds", C.c_uint32),
+                ("transformeds", C.c_void_p), ("n_transformeds", C.c_uint32),
+                ("materials", C.c_void_p), ("n_materials", C.c_uint32),
+                ("objects", C.c_void_p), ("n_objects", C.c_uint32),
+                ("lights", C.c_void_p), ("n_lights", C.c_uint32),
+                ("max_reflection_depth", C.c_uint32), ("reserved", C.c_uint32),
+                ("void_color", C.c_double * 3)]
+
+
+# ----------------------------------------------------------------------------- library loading
+_host = None
+_render = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(HOST_LIB)
+        L.rlh_last_error.restype = C.c_char_p
+        for n in ("rlh_rtiow_golden_test_scene", "rlh_rtiow_bouncing_spheres", "rlh_rtiow_cow_scene", "rlh_rtiow_from_spheres",
+                  "rlh_rtiow_desc", "rlh_rtc_test_obj_scene", "rlh_rtc_desc", "rlh_rtiow_output_ppm", "rlh_rtc_canvas_ppm"):
+            getattr(L, n).restype = C.c_void_p
+        L.rlh_rtiow_bouncing_spheres.argtypes = [C.c_uint64]
+        L.rlh_rtiow_cow_scene.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rlh_rtiow_from_spheres.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
+        L.rlh_rtiow_desc.argtypes = [C.c_void_p]
+        L.rlh_rtiow_free.argtypes = [C.c_void_p]
+        L.rlh_rtiow_get_params.argtypes = [C.c_void_p, C.POINTER(_HCameraParams)]
+        L.rlh_rtiow_camera_new.argtypes = [C.POINTER(_HCameraParams), C.POINTER(RtiowCamera)]
+        L.rlh_rtiow_output_ppm.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.rlh_free.argtypes = [C.c_void_p]
+        L.rlh_rtc_test_obj_scene.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.rlh_rtc_desc.argtypes = [C.c_void_p]
+        L.rlh_rtc_get_camera.argtypes = [C.c_void_p, C.POINTER(RtcCamera)]
+        L.rlh_rtc_free.argtypes = [C.c_void_p]
+        L.rlh_rtc_camera_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtcCamera)]
+        L.rlh_rtc_camera_from_matrix.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.POINTER(RtcCamera)]
+        L.rlh_rtc_make_transformed.argtypes = [C.c_void_p, C.c_void_p]
+        L.rlh_rtc_rotation.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.rlh_rtc_matmul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rlh_rtc_invert.argtypes = [C.c_void_p, C.c_void_p]
+        L.rlh_rtc_canvas_ppm.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        _host = L
+    return _host
+
+
+# every symbol include/rl_render.h declares (checked by tests/test_abi.py)
+RENDER_SYMBOLS = ["rl_init", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info", "rl_scene_destroy",
+                  "rl_rtiow_scene_create", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
+                  "rl_rtc_scene_create", "rl_rtc_render", "rl_rtc_render_rows", "rl_rtc_render_device"]
+
+
+def render_lib():
+    """The HIP product library. Fails loudly when it is not built."""
+    global _render
+    if _render is None:
+        if not os.path.exists(RENDER_LIB):
+            raise RuntimeError(f"{RENDER_LIB} not built — the HIP extension is required (no CPU fallback); "
+                               "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(RENDER_LIB)
+        L.rl_last_error.restype = C.c_char_p
+        L.rl_init.argtypes = [C.c_int]
+        L.rl_device_info.argtypes = [C.c_char_p, C.c_int]
+        L.rl_scene_destroy.argtypes = [C.c_void_p]
+        L.rl_rtiow_scene_create.restype = C.c_void_p
+        L.rl_rtiow_scene_create.argtypes = [C.c_void_p]
+        L.rl_rtc_scene_create.restype = C.c_void_p
+        L.rl_rtc_scene_create.argtypes = [C.c_void_p]
+        L.rl_rtiow_render.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_render_rows.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_render_device.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_render.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_render_rows.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_render_device.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        _render = L
+    return _render
+
+
+_inited = False
+
+
+def init(device=-1):
+    global _inited
+    L = render_lib()
+    rc = L.rl_init(int(device))
+    if rc != RL_OK:
+        raise RLError(rc, L.rl_last_error().decode())
+    _inited = True
+
+
+def _check(rc, allow_degenerate=False):
+    if rc == RL_OK or (allow_degenerate and rc == RL_E_DEGENERATE):
+        return rc
+    raise RLError(rc, render_lib().rl_last_error().decode())
+
+
+def rows_for(height, row_first, row_step):
+    return 0 if row_first >= height else (height - row_first + row_step - 1) // row_step
+
+
+# ----------------------------------------------------------------------------- RTIOW host mirror
+@dataclass
+class CameraParams:  # camera.rs:23-59, defaults as in the reference
+    aspect_ratio: float = 1.0
+    image_width: int = 100
+    samples_per_pixel: int = 10
+    max_depth: int = 10
+    vfov: float = 90.0
+    lookfrom: tuple = (0.0, 0.0, 0.0)
+    lookat: tuple = (0.0, 0.0, -1.0)
+    vup: tuple = (0.0, 1.0, 0.0)
+    defocus_angle: float = 0.0
+    focus_dist: float = 10.0
+    background: tuple = (0.7, 0.8, 1.0)
+    seed: int = 0
+
+    def _c(self):
+        p = _HCameraParams()
+        p.aspect_ratio, p.image_width, p.samples_per_pixel, p.max_depth = self.aspect_ratio, self.image_width, self.samples_per_pixel, self.max_depth
+        p.vfov, p.defocus_angle, p.focus_dist, p.seed = self.vfov, self.defocus_angle, self.focus_dist, self.seed
+        p.lookfrom[:], p.lookat[:], p.vup[:], p.background[:] = self.lookfrom, self.lookat, self.vup, self.background
+        return p
+
+    @staticmethod
+    def _from_c(p):
+        return CameraParams(p.aspect_ratio, p.image_width, p.samples_per_pixel, p.max_depth, p.vfov, tuple(p.lookfrom),
+                            tuple(p.lookat), tuple(p.vup), p.defocus_angle, p.focus_dist, tuple(p.background), p.seed)
+
+
+class World:
+    """A flattened RTIOW world (host arrays owned by librl_host) — what `world: H` is in camera.rs:122."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("host scene build failed: " + host_lib().rlh_last_error().decode())
+        self._h = handle
+        self.desc = host_lib().rlh_rtiow_desc(handle)
+        p = _HCameraParams()
+        host_lib().rlh_rtiow_get_params(handle, C.byref(p))
+        self.params = CameraParams._from_c(p)  # the example's / test's camera parameters
+        self._device = None
+
+    def __del__(self):
+        try:
+            if self._device is not None:
+                render_lib().rl_scene_destroy(self._device)
+            host_lib().rlh_rtiow_free(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def golden_test_scene():  # tests/ray_tracing_one_weekend.rs:14-75
+        return World(host_lib().rlh_rtiow_golden_test_scene())
+
+    @staticmethod
+    def bouncing_spheres(master_seed=1):  # examples/bouncing_spheres.rs
+        return World(host_lib().rlh_rtiow_bouncing_spheres(master_seed))
+
+    @staticmethod
+    def cow_scene(obj_text: bytes, rgb8: np.ndarray):  # examples/cow.rs
+        rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w = rgb8.shape[:2]
+        return World(host_lib().rlh_rtiow_cow_scene(obj_text, len(obj_text), rgb8.ctypes.data, w, h))
+
+    @staticmethod
+    def from_spheres(spheres, materials, textures, use_bvh):
+        spheres = np.ascontiguousarray(spheres, dtype=SPHERE)
+        materials = np.ascontiguousarray(materials, dtype=MATERIAL)
+        textures = np.ascontiguousarray(textures, dtype=TEXTURE)
+        return World(host_lib().rlh_rtiow_from_spheres(spheres.ctypes.data, len(spheres), materials.ctypes.data, len(materials),
+                                                       textures.ctypes.data, len(textures), 1 if use_bvh else 0))
+
+    def device(self):
+        """rl_rtiow_scene_create — uploads once, cached."""
+        if self._device is None:
+            if not _inited:
+                init()
+            L = render_lib()
+            h = L.rl_rtiow_scene_create(self.desc)
+            if not h:
+                raise RLError(RL_E_INVALID, L.rl_last_error().decode())
+            self._device = h
+        return self._device
+
+
+@dataclass
+class Canvas:  # camera.rs:263-296; data = SUMS over samples, [H, W, 3] f64
+    samples: int
+    width: int
+    height: int
+    data: np.ndarray = field(repr=False)
+
+    def merge(self, other):  # camera.rs:273-291
+        assert self.width == other.width and self.height == other.height and self.data.shape == other.data.shape
+        return Canvas(self.samples + other.samples, self.width, self.height, self.data + other.data)
+
+    def pixel_data(self):  # camera.rs:293: c / samples == c * (1/samples)
+        return self.data * (1.0 / self.samples)
+
+
+class Camera:
+    def __init__(self, params: CameraParams):  # Camera::new camera.rs:72
+        self.params = params
+        self.c = RtiowCamera()
+        pc = params._c()
+        if host_lib().rlh_rtiow_camera_new(C.byref(pc), C.byref(self.c)) != 0:
+            raise RuntimeError("Camera::new: " + host_lib().rlh_last_error().decode())
+        self.image_height = self.c.image_height
+
+    def _render(self, first_sample, world: World, row_first=0, row_step=1, stats=None, allow_degenerate=False):
+        nrows = rows_for(self.c.image_height, row_first, row_step)
+        out = np.empty((nrows, self.c.image_width, 3), dtype=np.float64)
+        st = Stats()
+        rc = render_lib().rl_rtiow_render_rows(world.device(), C.byref(self.c), first_sample, row_first, row_step, out.ctypes.data, C.byref(st))
+        _check(rc, allow_degenerate)
+        if stats is not None:
+            stats.update(st.as_dict())
+            stats["rc"] = rc
+        return out
+
+    def render(self, world: World, stats=None, allow_degenerate=False) -> Canvas:  # camera.rs:122
+        data = self._render(0, world, stats=stats, allow_degenerate=allow_degenerate)
+        return Canvas(self.params.samples_per_pixel, self.c.image_width, self.c.image_height, data)
+
+    def render_from_checkpoint(self, world: World, checkpoint: Canvas) -> Canvas:  # camera.rs:136-143
+        data = self._render(checkpoint.samples, world)
+        return Canvas(self.params.samples_per_pixel, self.c.image_width, self.c.image_height, data).merge(checkpoint)
+
+    def render_rows(self, world: World, row_first, row_step, first_sample=0, stats=None):
+        return self._render(first_sample, world, row_first, row_step, stats)
+
+    def render_device(self, world: World, d_ptr, stream=0, row_first=0, row_step=1, first_sample=0, stats=None):
+        """Output stays in HBM: d_ptr = device pointer of nrows*W*3 f64. Async unless stats is a dict."""
+        st = Stats() if stats is not None else None
+        rc = render_lib().rl_rtiow_render_device(world.device(), C.byref(self.c), first_sample, row_first, row_step,
+                                                 C.c_void_p(d_ptr), C.c_void_p(stream), C.byref(st) if st is not None else None)
+        _check(rc)
+        if stats is not None:
+            stats.update(st.as_dict())
+
+
+def _take_string(ptr, n):
+    s = C.string_at(ptr, n.value)
+    host_lib().rlh_free(ptr)
+    return s.decode("ascii")
+
+
+def output_ppm(canvas_or_sums, samples=None) -> str:  # output.rs:5-14
+    if isinstance(canvas_or_sums, Canvas):
+        data, samples = canvas_or_sums.data, canvas_or_sums.samples
+    else:
+        data = canvas_or_sums
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    h, w = data.shape[:2]
+    n = C.c_uint64()
+    return _take_string(host_lib().rlh_rtiow_output_ppm(data.ctypes.data, w, h, samples, C.byref(n)), n)
+
+
+# ----------------------------------------------------------------------------- RTC host mirror
+class RtcWorld:
+    """A flattened ray-tracer-challenge World (scene/world.rs:26) + the scene's Camera."""
+
+    def __init__(self, handle=None, desc_struct=None, keep=None, camera=None):
+        self._h = handle
+        self._keep = keep
+        self._device = None
+        if handle is not None:
+            if not handle:
+                raise RuntimeError("host scene build failed: " + host_lib().rlh_last_error().decode())
+            self.desc = host_lib().rlh_rtc_desc(handle)
+            self.camera = RtcCamera()
+            host_lib().rlh_rtc_get_camera(handle, C.byref(self.camera))
+        else:
+            self._desc_struct = desc_struct
+            self.desc = C.addressof(desc_struct)
+            self.camera = camera
+
+    def __del__(self):
+        try:
+            if self._device is not None:
+                render_lib().rl_scene_destroy(self._device)
+            if self._h:
+                host_lib().rlh_rtc_free(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def test_obj_scene(obj_text: bytes, res_x=300, res_y=200):  # tests/ray_tracer.rs:242-275
+        return RtcWorld(host_lib().rlh_rtc_test_obj_scene(obj_text, len(obj_text), res_x, res_y))
+
+    @staticmethod
+    def from_arrays(triangles, materials, objects, lights, groups=(), group_items=(), boundeds=(), transformeds=(),
+                    max_reflection_depth=5, void_color=(0.0, 0.0, 0.0), camera=None):
+        arrs = dict(triangles=np.ascontiguousarray(triangles, dtype=RTC_TRIANGLE), groups=np.ascontiguousarray(groups, dtype=RTC_GROUP),
+                    group_items=np.ascontiguousarray(group_items, dtype=HREF), boundeds=np.ascontiguousarray(boundeds, dtype=RTC_BOUNDED),
+                    transformeds=np.ascontiguousarray(transformeds, dtype=RTC_TRANSFORMED),
+                    materials=np.ascontiguousarray(materials, dtype=RTC_MATERIAL), objects=np.ascontiguousarray(objects, dtype=HREF),
+                    lights=np.ascontiguousarray(lights, dtype=RTC_LIGHT))
+        d = RtcSceneDesc()
+        for k, a in arrs.items():
+            setattr(d, k, a.ctypes.data if len(a) else None)
+            setattr(d, "n_" + k, len(a))
+        d.max_reflection_depth = max_reflection_depth
+        d.void_color[:] = void_color
+        return RtcWorld(desc_struct=d, keep=arrs, camera=camera)
+
+    def device(self):
+        if self._device is None:
+            if not _inited:
+                init()
+            L = render_lib()
+            h = L.rl_rtc_scene_create(self.desc)
+            if not h:
+                raise RLError(RL_E_INVALID, L.rl_last_error().decode())
+            self._device = h
+        return self._device
+
+    def render(self, aa_samples=1, camera=None, row_first=0, row_step=1, stats=None, allow_degenerate=False):
+        """Camera::render(&world, &RenderOpts{anti_aliasing_samples}) on the GPU -> [rows, W, 3] means."""
+        cam = camera or self.camera
+        nrows = rows_for(cam.vsize, row_first, row_step)
+        out = np.empty((nrows, cam.hsize, 3), dtype=np.float64)
+        st = Stats()
+        rc = render_lib().rl_rtc_render_rows(self.device(), C.byref(cam), aa_samples, row_first, row_step, out.ctypes.data, C.byref(st))
+        _check(rc, allow_degenerate)
+        if stats is not None:
+            stats.update(st.as_dict())
+            stats["rc"] = rc
+        return out
+
+    def render_device(self, d_ptr, aa_samples=1, camera=None, stream=0, row_first=0, row_step=1, stats=None):
+        cam = camera or self.camera
+        st = Stats() if stats is not None else None
+        rc = render_lib().rl_rtc_render_device(self.device(), C.byref(cam), aa_samples, row_first, row_step, C.c_void_p(d_ptr),
+                                               C.c_void_p(stream), C.byref(st) if st is not None else None)
+        _check(rc)
+        if stats is not None:
+            stats.update(st.as_dict())
+
+
+def rtc_camera(hsize, vsize, fov, frm, to, up) -> RtcCamera:  # Camera::new + view_transform
+    c = RtcCamera()
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (frm, to, up)]
+    if host_lib().rlh_rtc_camera_new(hsize, vsize, fov, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, C.byref(c)) != 0:
+        raise RuntimeError("rtc Camera::new: " + host_lib().rlh_last_error().decode())
+    return c
+
+
+def rtc_transformed(matrix4, child_kind, child_index):
+    """Transformed::new(child, transform): one RTC_TRANSFORMED record (inverse + inverse-transpose by cofactors)."""
+    rec = np.zeros(1, dtype=RTC_TRANSFORMED)
+    m = np.ascontiguousarray(matrix4, dtype=np.float64).reshape(16)
+    if host_lib().rlh_rtc_make_transformed(m.ctypes.data, rec.ctypes.data) != 0:
+        raise RuntimeError("Matrix is not invertible.")
+    rec["child"]["kind"], rec["child"]["index"] = child_kind, child_index
+    return rec[0]
+
+
+def canvas_ppm(rgb) -> str:  # draw/canvas.rs:50-97
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w = rgb.shape[:2]
+    n = C.c_uint64()
+    return _take_string(host_lib().rlh_rtc_canvas_ppm(rgb.ctypes.data, w, h, C.byref(n)), n)

@@ -1,0 +1,254 @@
+// C entry points over the C++ host mirror (rtiow_host.hpp / rtc_host.hpp / scenes.hpp) so that
+// Python (ctypes) tests and bench.py can build the reference's scenes, derive cameras, flatten to
+// the rl_render.h descriptors and encode PPMs.  Also defines Camera::render (both crates) on top of
+// the C ABI — the call a Rust maintainer would add as `Camera::render_gpu`.
+#include <cstdio>
+#include <cstdlib>
+
+#include "scenes.hpp"
+
+extern "C" {
+
+struct rlh_camera_params {  // POD mirror of rtiow::CameraParams (camera.rs:23-39)
+  double aspect_ratio;
+  uint64_t image_width, samples_per_pixel, max_depth;
+  double vfov;
+  double lookfrom[3], lookat[3], vup[3];
+  double defocus_angle, focus_dist;
+  double background[3];
+  uint64_t seed;
+};
+
+struct rlh_rtiow {
+  rtiow::Flattened flat;
+  rl_rtiow_scene_desc desc;
+  rtiow::CameraParams params;
+};
+
+static thread_local std::string g_err;
+const char *rlh_last_error() { return g_err.c_str(); }
+
+static rlh_rtiow *finish(scenes::RtiowScene &&s) {
+  auto *h = new rlh_rtiow();
+  h->flat.root = s.world->flatten(h->flat);
+  h->desc = h->flat.desc();
+  h->params = s.params;
+  return h;
+}
+
+rlh_rtiow *rlh_rtiow_golden_test_scene() {
+  try {
+    return finish(scenes::golden_test_scene());
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+rlh_rtiow *rlh_rtiow_bouncing_spheres(uint64_t master_seed) {
+  try {
+    return finish(scenes::bouncing_spheres(master_seed));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+rlh_rtiow *rlh_rtiow_cow_scene(const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h) {
+  try {
+    return finish(scenes::cow_scene(std::string(obj_text, obj_len), rgb8, w, h));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+// Generic: a world of spheres, either a plain slice (use_bvh=0, `[Sphere]`) or Bvh::new(spheres).
+// materials/textures are rl_render.h PODs; sphere.material indexes `materials`.
+rlh_rtiow *rlh_rtiow_from_spheres(const rl_sphere *spheres, uint32_t n, const rl_material *materials, uint32_t n_mat,
+                                  const rl_texture *textures, uint32_t n_tex, int use_bvh) {
+  try {
+    using namespace rtiow;
+    std::vector<TexturePtr> tex(n_tex);
+    // textures may reference later ids (checker): two passes
+    for (uint32_t i = 0; i < n_tex; i++) tex[i] = std::make_shared<Texture>();
+    for (uint32_t i = 0; i < n_tex; i++) {
+      const rl_texture &t = textures[i];
+      tex[i]->kind = t.kind;
+      tex[i]->color = Color(t.color[0], t.color[1], t.color[2]);
+      tex[i]->inv_scale = t.inv_scale;
+      if (t.kind == RL_TEX_CHECKER) {
+        if (t.even >= n_tex || t.odd >= n_tex) throw std::runtime_error("texture index out of range");
+        tex[i]->even = tex[t.even];
+        tex[i]->odd = tex[t.odd];
+      } else if (t.kind != RL_TEX_SOLID)
+        throw std::runtime_error("only solid/checker textures here");
+    }
+    std::vector<MaterialPtr> mats(n_mat);
+    for (uint32_t i = 0; i < n_mat; i++) {
+      const rl_material &m = materials[i];
+      auto p = std::make_shared<Material>();
+      p->kind = m.kind;
+      if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+        if (m.texture >= n_tex) throw std::runtime_error("material texture out of range");
+        p->texture = tex[m.texture];
+      }
+      p->albedo = Color(m.albedo[0], m.albedo[1], m.albedo[2]);
+      p->fuzz = m.fuzz;
+      p->ior = m.ior;
+      mats[i] = p;
+    }
+    std::vector<HittablePtr> hs;
+    for (uint32_t i = 0; i < n; i++) {
+      const rl_sphere &s = spheres[i];
+      if (s.material >= n_mat) throw std::runtime_error("sphere material out of range");
+      Center c = s.moving ? Center::Moving(Point3(s.center0[0], s.center0[1], s.center0[2]), Point3(s.center1[0], s.center1[1], s.center1[2]))
+                          : Center::Stationary(Point3(s.center0[0], s.center0[1], s.center0[2]));
+      hs.push_back(std::make_shared<Sphere>(c, s.radius, mats[s.material]));
+    }
+    scenes::RtiowScene sc;
+    if (use_bvh) sc.world = std::make_shared<Bvh>(std::move(hs));
+    else sc.world = std::make_shared<HittableList>(std::move(hs));
+    return finish(std::move(sc));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+const rl_rtiow_scene_desc *rlh_rtiow_desc(const rlh_rtiow *h) { return &h->desc; }
+void rlh_rtiow_free(rlh_rtiow *h) { delete h; }
+
+void rlh_rtiow_get_params(const rlh_rtiow *h, rlh_camera_params *o) {
+  const auto &p = h->params;
+  o->aspect_ratio = p.aspect_ratio;
+  o->image_width = p.image_width, o->samples_per_pixel = p.samples_per_pixel, o->max_depth = p.max_depth;
+  o->vfov = p.vfov;
+  rtiow::put3(o->lookfrom, p.lookfrom), rtiow::put3(o->lookat, p.lookat), rtiow::put3(o->vup, p.vup);
+  o->defocus_angle = p.defocus_angle, o->focus_dist = p.focus_dist;
+  rtiow::put3(o->background, p.background);
+  o->seed = p.seed;
+}
+
+static rtiow::CameraParams to_params(const rlh_camera_params *i) {
+  rtiow::CameraParams p;
+  p.aspect_ratio = i->aspect_ratio;
+  p.image_width = i->image_width, p.samples_per_pixel = i->samples_per_pixel, p.max_depth = i->max_depth;
+  p.vfov = i->vfov;
+  p.lookfrom = rtiow::Point3(i->lookfrom[0], i->lookfrom[1], i->lookfrom[2]);
+  p.lookat = rtiow::Point3(i->lookat[0], i->lookat[1], i->lookat[2]);
+  p.vup = rtiow::Vec3(i->vup[0], i->vup[1], i->vup[2]);
+  p.defocus_angle = i->defocus_angle, p.focus_dist = i->focus_dist;
+  p.background = rtiow::Color(i->background[0], i->background[1], i->background[2]);
+  p.seed = i->seed;
+  return p;
+}
+
+// Camera::new (camera.rs:72-118). Returns 0, or -1 where the reference would panic (unwrap on a
+// degenerate basis, camera.rs:86-88).
+int rlh_rtiow_camera_new(const rlh_camera_params *in, rl_rtiow_camera *out) {
+  try {
+    rtiow::Camera cam(to_params(in));
+    *out = cam.derived();
+    return 0;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+static char *dup_string(const std::string &s, uint64_t *len) {
+  char *p = (char *)std::malloc(s.size() + 1);
+  std::memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  if (len) *len = s.size();
+  return p;
+}
+void rlh_free(void *p) { std::free(p); }
+
+char *rlh_rtiow_output_ppm(const double *rgb_sum, uint64_t w, uint64_t h, uint64_t samples, uint64_t *len) {
+  return dup_string(rtiow::output_ppm(rgb_sum, w, h, samples), len);
+}
+
+// ------------------------------------------------------------------ RTC
+struct rlh_rtc {
+  rtc::Flattened flat;
+  rl_rtc_scene_desc desc;
+  rl_rtc_camera camera;
+};
+
+rlh_rtc *rlh_rtc_test_obj_scene(const char *obj_text, uint64_t obj_len, uint64_t res_x, uint64_t res_y) {
+  try {
+    auto s = scenes::rtc_test_obj_scene(std::string(obj_text, obj_len), res_x, res_y);
+    auto *h = new rlh_rtc();
+    s.world.flatten(h->flat);
+    h->desc = h->flat.desc();
+    h->camera = s.camera->derived();
+    return h;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+const rl_rtc_scene_desc *rlh_rtc_desc(const rlh_rtc *h) { return &h->desc; }
+void rlh_rtc_get_camera(const rlh_rtc *h, rl_rtc_camera *out) { *out = h->camera; }
+void rlh_rtc_free(rlh_rtc *h) { delete h; }
+
+// Camera::new(hsize, vsize, fov, view_transform(from,to,up))  (scene/camera.rs:35, transformation.rs:74)
+int rlh_rtc_camera_new(uint64_t hsize, uint64_t vsize, double fov, const double *from, const double *to, const double *up, rl_rtc_camera *out) {
+  try {
+    using namespace rtc;
+    Camera c(hsize, vsize, fov,
+             InvertibleMatrix4::try_from(transformation::view_transform(Point3d{from[0], from[1], from[2]}, Point3d{to[0], to[1], to[2]}, Vec3d{up[0], up[1], up[2]})));
+    *out = c.derived();
+    return 0;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+// Camera::new with an explicit 4x4 transform (row-major); returns -1 if not invertible
+int rlh_rtc_camera_from_matrix(uint64_t hsize, uint64_t vsize, double fov, const double *m16, rl_rtc_camera *out) {
+  try {
+    rtc::Matrix4 M;
+    std::memcpy(M.m, m16, sizeof M.m);
+    rtc::Camera c(hsize, vsize, fov, rtc::InvertibleMatrix4::try_from(M));
+    *out = c.derived();
+    return 0;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+// Transformed::new(child, transform) helper for Python-built scenes: fills inverse + inverse_transpose
+int rlh_rtc_make_transformed(const double *m16, rl_rtc_transformed *out) {
+  rtc::Matrix4 M, inv;
+  std::memcpy(M.m, m16, sizeof M.m);
+  if (!rtc::invert(M, inv)) return -1;
+  rtc::Matrix4 it = inv.transpose();
+  std::memcpy(out->inverse, inv.m, sizeof inv.m);
+  std::memcpy(out->inverse_transpose, it.m, sizeof it.m);
+  return 0;
+}
+// transformation::{translation,scaling,rotation_*,view_transform}, sequence — exposed for tests
+void rlh_rtc_rotation(int axis, double radians, double *out16) {
+  rtc::Matrix4 m = axis == 0 ? rtc::transformation::rotation_x(radians) : axis == 1 ? rtc::transformation::rotation_y(radians) : rtc::transformation::rotation_z(radians);
+  std::memcpy(out16, m.m, sizeof m.m);
+}
+void rlh_rtc_matmul(const double *a16, const double *b16, double *out16) {
+  rtc::Matrix4 A, B;
+  std::memcpy(A.m, a16, sizeof A.m);
+  std::memcpy(B.m, b16, sizeof B.m);
+  rtc::Matrix4 C = A.mul(B);
+  std::memcpy(out16, C.m, sizeof C.m);
+}
+int rlh_rtc_invert(const double *m16, double *out16) {
+  rtc::Matrix4 M, inv;
+  std::memcpy(M.m, m16, sizeof M.m);
+  if (!rtc::invert(M, inv)) return -1;
+  std::memcpy(out16, inv.m, sizeof inv.m);
+  return 0;
+}
+
+char *rlh_rtc_canvas_ppm(const double *rgb, uint64_t w, uint64_t h, uint64_t *len) { return dup_string(rtc::canvas_ppm(rgb, w, h), len); }
+
+}  // extern "C"
+

@@ -1,0 +1,310 @@
+// Scene definitions used as INPUTS by tests and bench: the reference's own test scenes and
+// example scenes, restated (values, not code) on top of rtiow_host.hpp / rtc_host.hpp.
+//   golden_test_scene      <- ray-tracing-one-weekend/tests/ray_tracing_one_weekend.rs:14-75
+//   bouncing_spheres       <- ray-tracing-one-weekend/examples/bouncing_spheres.rs:15-134
+//   rtc_test_obj_scene     <- ray-tracer-challenge/tests/ray_tracer.rs:242-275
+//   rtiow WavefrontObj     <- ray-tracing-one-weekend/src/io/wavefront_obj.rs
+//   cow_scene              <- ray-tracing-one-weekend/examples/cow.rs:32-136
+#pragma once
+#include "rtc_host.hpp"
+#include "rtiow_host.hpp"
+
+namespace scenes {
+
+// std::f64::consts (M_PI/3.0 is NOT FRAC_PI_3 in binary64 — differs by one ulp)
+static const double FRAC_PI_2 = 1.57079632679489661923132169163975144;
+static const double FRAC_PI_3 = 1.04719755119659774615421446109316763;
+static const double FRAC_PI_6 = 0.52359877559829887307710723054658381;
+
+// rand_xoshiro 0.6.0 Xoshiro256PlusPlus with SplitMix64 seed_from_u64; rand 0.8.5 Standard f64 and
+// gen_range(lo..hi).  UNPINNED by any reference test: published algorithm only.
+struct Xoshiro256PlusPlus {
+  uint64_t s[4];
+  static Xoshiro256PlusPlus seed_from_u64(uint64_t x) {
+    Xoshiro256PlusPlus r;
+    for (int i = 0; i < 4; i++) {
+      x += 0x9e3779b97f4a7c15ull;
+      uint64_t z = x;
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      r.s[i] = z ^ (z >> 31);
+    }
+    return r;
+  }
+  static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+  uint64_t next_u64() {
+    uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return result;
+  }
+  double gen_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+  double gen_range(double lo, double hi) {
+    double scale = hi - lo;
+    for (;;) {
+      uint64_t bits = (next_u64() >> 12) | 0x3FF0000000000000ull;
+      double v12;
+      std::memcpy(&v12, &bits, 8);
+      double res = (v12 - 1.0) * scale + lo;
+      if (res < hi) return res;
+    }
+  }
+};
+
+struct RtiowScene {
+  std::shared_ptr<rtiow::Hittable> world;
+  rtiow::CameraParams params;
+};
+
+inline RtiowScene golden_test_scene() {
+  using namespace rtiow;
+  std::vector<HittablePtr> w;
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, -100.5, -1.0)), 100.0, Lambertian(SolidColor(Color(0.8, 0.8, 0.0)))));
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 0.0, -1.2)), 0.5, Lambertian(SolidColor(Color(0.1, 0.2, 0.5)))));
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(-1.0, 0.0, -1.0)), 0.5, Dielectric(1.5)));
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(-1.0, 0.0, -1.0)), 0.4, Dielectric(1.0 / 1.5)));
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(1.0, 0.0, -1.0)), 0.5, Metal(Color(0.8, 0.6, 0.2), 1.0)));
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0;
+  p.image_width = 300;
+  p.samples_per_pixel = 10;
+  p.max_depth = 10;
+  p.vfov = 20.0;
+  p.lookfrom = Point3(-2.0, 2.0, 1.0);
+  p.lookat = Point3(0.0, 0.0, -1.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 10.0;
+  p.focus_dist = 3.4;
+  p.background = Color(0.7, 0.8, 1.0);
+  p.seed = 0;
+  return RtiowScene{std::make_shared<HittableList>(std::move(w)), p};
+}
+
+// grid_half = 11 reproduces the example; the camera is the example's with max_depth left to the caller
+inline RtiowScene bouncing_spheres(uint64_t master_seed = 1) {
+  using namespace rtiow;
+  auto rng = Xoshiro256PlusPlus::seed_from_u64(master_seed);
+  std::vector<HittablePtr> world;
+  auto checker = Checker(0.32, SolidColor(Color(0.2, 0.23, 0.1)), SolidColor(Color(0.9, 0.9, 0.9)));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, -1000.0, 0.0)), 1000.0, Lambertian(checker)));
+  for (int a = -11; a < 11; a++)
+    for (int b = -11; b < 11; b++) {
+      double choose_mat = rng.gen_f64();
+      double cx = (double)a + 0.9 * rng.gen_f64();
+      double cz = (double)b + 0.9 * rng.gen_f64();
+      Point3 center_point(cx, 0.2, cz);
+      if ((center_point - Point3(4.0, 0.2, 0.0)).length() > 0.9) {
+        if (choose_mat < 0.8) {
+          Point3 center2 = center_point + Vec3(0.0, rng.gen_range(0.0, 0.5), 0.0);
+          double r1 = rng.gen_f64(), g1 = rng.gen_f64(), b1 = rng.gen_f64();
+          double r2 = rng.gen_f64(), g2 = rng.gen_f64(), b2 = rng.gen_f64();
+          Color albedo = Color(r1, g1, b1) * Color(r2, g2, b2);
+          world.push_back(std::make_shared<Sphere>(Center::Moving(center_point, center2), 0.2, Lambertian(SolidColor(albedo))));
+        } else if (choose_mat < 0.95) {
+          double r = rng.gen_range(0.5, 1.0), g = rng.gen_range(0.5, 1.0), bb = rng.gen_range(0.5, 1.0);
+          double fuzz = rng.gen_f64();
+          world.push_back(std::make_shared<Sphere>(Center::Stationary(center_point), 0.2, Metal(Color(r, g, bb), fuzz)));
+        } else {
+          world.push_back(std::make_shared<Sphere>(Center::Stationary(center_point), 0.2, Dielectric(1.5)));
+        }
+      }
+    }
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 1.0, 0.0)), 1.0, Dielectric(1.5)));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(-4.0, 1.0, 0.0)), 1.0, Lambertian(SolidColor(Color(0.4, 0.2, 0.1)))));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(4.0, 1.0, 0.0)), 1.0, Metal(Color(0.7, 0.6, 0.5), 0.0)));
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0;
+  p.image_width = 400;
+  p.samples_per_pixel = 100;
+  p.max_depth = 10;
+  p.vfov = 20.0;
+  p.lookfrom = Point3(13.0, 2.0, 3.0);
+  p.lookat = Point3(0.0, 0.0, 0.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.6;
+  p.focus_dist = 10.0;
+  return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
+}
+
+// ------------------------------------------------------------------ RTIOW OBJ loader (io/wavefront_obj.rs)
+// v / vt / vn / f / g; fan triangulation; per-triangle Option<uvs>, Option<normals>; -> Bvh<Triangle>
+struct RtiowObj {
+  struct Tri {
+    rtiow::Point3 p[3];
+    bool has_uv, has_n;
+    double uv[6];
+    rtiow::Vec3 n[3];
+  };
+  std::vector<std::pair<std::string, std::vector<Tri>>> groups;
+  std::vector<rtiow::Point3> vertices;
+  std::vector<rtiow::Vec3> normals;
+  std::vector<std::pair<double, double>> texcoords;
+  uint32_t ignored = 0;
+
+  static RtiowObj parse(const std::string &content) {
+    RtiowObj obj;
+    std::string current_name = "\x01" "default";
+    std::vector<Tri> current;
+    auto commit = [&](const std::string &name, std::vector<Tri> &&val) {
+      for (auto &g : obj.groups)
+        if (g.first == name) {
+          g.second = std::move(val);
+          return;
+        }
+      obj.groups.emplace_back(name, std::move(val));
+    };
+    std::istringstream in(content);
+    std::string line;
+    while (std::getline(in, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      size_t sp = line.find(' ');
+      bool ok = false;
+      if (sp != std::string::npos) {
+        std::string head = line.substr(0, sp), tail = line.substr(sp + 1);
+        size_t a = tail.find_first_not_of(" \t\r\n\f\v"), b = tail.find_last_not_of(" \t\r\n\f\v");
+        std::string trimmed = a == std::string::npos ? "" : tail.substr(a, b - a + 1);
+        std::vector<double> ns;
+        if (head == "v") {
+          if (rtc::WavefrontObj::parse_floats(trimmed, ns) && ns.size() == 3) obj.vertices.emplace_back(ns[0], ns[1], ns[2]), ok = true;
+        } else if (head == "vn") {
+          if (rtc::WavefrontObj::parse_floats(trimmed, ns) && ns.size() == 3) obj.normals.emplace_back(ns[0], ns[1], ns[2]), ok = true;
+        } else if (head == "vt") {  // :107-118: 1 value -> (u,0); >=2 -> (u,v)
+          if (rtc::WavefrontObj::parse_floats(trimmed, ns) && !ns.empty()) obj.texcoords.emplace_back(ns[0], ns.size() > 1 ? ns[1] : 0.0), ok = true;
+        } else if (head == "f") {
+          std::vector<Tri> ts;
+          if (obj.parse_face(trimmed, ts)) current.insert(current.end(), ts.begin(), ts.end()), ok = true;
+        } else if (head == "g") {
+          commit(current_name, std::move(current));
+          current.clear();
+          current_name = trimmed;
+          ok = true;
+        }
+      }
+      if (!ok) obj.ignored++;
+    }
+    commit(current_name, std::move(current));
+    return obj;
+  }
+  bool parse_face(const std::string &tail, std::vector<Tri> &out) const {  // :150-240
+    struct VTN {
+      size_t v;
+      bool ht, hn;
+      size_t t, n;
+    };
+    std::vector<VTN> idx;
+    std::istringstream ss(tail);
+    std::string token;
+    while (ss >> token) {
+      std::vector<std::string> parts;
+      size_t start = 0;
+      for (;;) {
+        size_t p = token.find('/', start);
+        if (p == std::string::npos) {
+          parts.push_back(token.substr(start));
+          break;
+        }
+        parts.push_back(token.substr(start, p - start));
+        start = p + 1;
+      }
+      if (parts.size() < 1 || parts.size() > 3) return false;
+      VTN e{0, false, false, 0, 0};
+      if (!rtc::WavefrontObj::parse_usize(parts[0], e.v)) return false;
+      if (parts.size() >= 2 && !parts[1].empty()) e.ht = rtc::WavefrontObj::parse_usize(parts[1], e.t);  // bad index -> None
+      if (parts.size() == 3) e.hn = rtc::WavefrontObj::parse_usize(parts[2], e.n);
+      idx.push_back(e);
+    }
+    for (auto &e : idx) {
+      if (e.v < 1 || e.v > vertices.size()) throw std::runtime_error("obj: vertex index out of range");
+      if (e.ht && (e.t < 1 || e.t > texcoords.size())) throw std::runtime_error("obj: texcoord index out of range");
+      if (e.hn && (e.n < 1 || e.n > normals.size())) throw std::runtime_error("obj: normal index out of range");
+    }
+    if (idx.size() < 3) return false;
+    for (size_t i = 2; i < idx.size(); i++) {
+      const VTN *vs[3] = {&idx[0], &idx[i - 1], &idx[i]};
+      Tri t{};
+      for (int k = 0; k < 3; k++) t.p[k] = vertices[vs[k]->v - 1];
+      t.has_uv = vs[0]->ht && vs[1]->ht && vs[2]->ht;
+      t.has_n = vs[0]->hn && vs[1]->hn && vs[2]->hn;
+      if (t.has_uv)
+        for (int k = 0; k < 3; k++) t.uv[2 * k] = texcoords[vs[k]->t - 1].first, t.uv[2 * k + 1] = texcoords[vs[k]->t - 1].second;
+      if (t.has_n)
+        for (int k = 0; k < 3; k++) t.n[k] = normals[vs[k]->n - 1];
+      out.push_back(t);
+    }
+    return true;
+  }
+  std::shared_ptr<rtiow::Bvh> to_object(rtiow::MaterialPtr material) const {  // :84-100
+    std::vector<rtiow::HittablePtr> tris;
+    for (auto &g : groups)
+      for (auto &t : g.second) tris.push_back(std::make_shared<rtiow::Triangle>(t.p, t.has_uv ? t.uv : nullptr, t.has_n ? t.n : nullptr, material));
+    return std::make_shared<rtiow::Bvh>(std::move(tris));
+  }
+};
+
+// examples/cow.rs scene. rgb8: the decoded spot_texture.png (w*h*3 bytes, top row first).
+// image crate into_rgb32f: u8 -> f32 via (v as f32)/255.0; then srgb_to_linear(u as f64) as f32 (cow.rs:27-29).
+inline RtiowScene cow_scene(const std::string &obj_text, const uint8_t *rgb8, uint32_t tw, uint32_t th) {
+  using namespace rtiow;
+  auto img = std::make_shared<ImageData>();
+  img->width = tw, img->height = th;
+  img->rgb.resize((size_t)tw * th * 3);
+  for (size_t i = 0; i < img->rgb.size(); i++) {
+    float u = (float)rgb8[i] / 255.0f;
+    img->rgb[i] = (float)srgb::srgb_to_linear((double)u);
+  }
+  auto cow_surface = Lambertian(Image(img));
+  auto cow = RtiowObj::parse(obj_text).to_object(cow_surface);
+  HittablePtr transformed_cow =
+      std::make_shared<Translate>(Transform::rotate_y(Transform::scale(cow, 200.0), 45.0), Vec3(240.0, 165.0, 240.0));
+  auto red = Lambertian(SolidColor(Color(0.65, 0.05, 0.05)));
+  auto white = Lambertian(SolidColor(Color(0.73, 0.73, 0.73)));
+  auto green = Lambertian(SolidColor(Color(0.12, 0.45, 0.15)));
+  auto light = DiffuseLight(SolidColor(Color(5.0, 5.0, 5.0)));
+  std::vector<HittablePtr> world;
+  world.push_back(std::make_shared<Quad>(Point3(555, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), green));
+  world.push_back(std::make_shared<Quad>(Point3(0, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), red));
+  world.push_back(std::make_shared<Quad>(Point3(113, 554, 127), Vec3(330, 0, 0), Vec3(0, 0, 305), light));
+  world.push_back(std::make_shared<Quad>(Point3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+  world.push_back(std::make_shared<Quad>(Point3(555, 555, 555), Vec3(-555, 0, 0), Vec3(0, 0, -555), white));
+  world.push_back(std::make_shared<Quad>(Point3(0, 0, 555), Vec3(555, 0, 0), Vec3(0, 555, 0), white));
+  world.push_back(transformed_cow);
+  CameraParams p;
+  p.aspect_ratio = 1.0;
+  p.image_width = 600;
+  p.samples_per_pixel = 200;
+  p.max_depth = 40;
+  p.background = Color(0.0, 0.0, 0.0);
+  p.vfov = 40.0;
+  p.lookfrom = Point3(278.0, 278.0, -800.0);
+  p.lookat = Point3(278.0, 278.0, 0.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.0;
+  return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
+}
+
+// ------------------------------------------------------------------ RTC
+struct RtcScene {
+  rtc::World world;
+  std::shared_ptr<rtc::Camera> camera;
+};
+
+inline RtcScene rtc_test_obj_scene(const std::string &teapot_obj_text, size_t res_x = 300, size_t res_y = 200) {
+  using namespace rtc;
+  auto obj = std::make_shared<Transformed>(
+      WavefrontObj::parse(teapot_obj_text).to_object(),
+      InvertibleMatrix4::try_from(transformation::sequence({transformation::rotation_x(-FRAC_PI_2)})));
+  RtcScene s;
+  s.world.objects.push_back(obj);
+  s.world.lights.push_back(PointLight{Point3d{-2.0, 20.0, -30.0}, Color{1.0, 1.0, 1.0}});
+  Point3d from{0.0, 15.0, -30.0}, to{0.0, 5.0, 0.0};
+  Vec3d up{0.0, 1.0, 0.0};
+  s.camera = std::make_shared<Camera>(res_x, res_y, FRAC_PI_3, InvertibleMatrix4::try_from(transformation::view_transform(from, to, up)));
+  return s;
+}
+
+}  // namespace scenes

@@ -1,0 +1,52 @@
+"""Pins the CPU oracle (oracle/rl_oracle.cpp) + the host mirror (scene building, Camera::new, OBJ
+loader, PPM writers) against the reference's own golden images, byte for byte.
+
+  test.ppm            <- ray-tracing-one-weekend/tests/ray_tracing_one_weekend.rs:77-95 (test_render)
+  test_obj_scene.ppm  <- ray-tracer-challenge/tests/ray_tracer.rs:242-275 (obj_scene)
+"""
+import hashlib
+
+import numpy as np
+
+
+def test_rtiow_golden_ppm_byte_exact(rl, oracle, golden):
+    expected = golden("test.ppm.gz")
+    assert hashlib.md5(expected).hexdigest() == "82065c4eb1254a68ded2541845634194"
+    world = rl.World.golden_test_scene()
+    cam = rl.Camera(world.params)
+    assert (cam.c.image_width, cam.c.image_height) == (300, 168)
+    sums = oracle.rtiow_render(world.desc, cam.c)
+    ppm = rl.output_ppm(sums, world.params.samples_per_pixel)
+    assert ppm.encode() == expected
+
+
+def test_rtiow_camera_self_check(rl):
+    # derived camera of the golden scene
+    cam = rl.Camera(rl.World.golden_test_scene().params)
+    assert tuple(cam.c.pixel_00) == (-0.5481908409049292, 0.523594679927457, -1.9607582665665697)
+    assert tuple(cam.c.pixel_du)[0] == 0.005046652533349494 and tuple(cam.c.pixel_du)[2] == 0.005046652533349494
+
+
+def test_rtiow_pixel_sums_and_word_positions(rl, oracle):
+    # per-pixel f64 sums over the 10 samples and the final ChaCha word position
+    world = rl.World.golden_test_scene()
+    cam = rl.Camera(world.params)
+    table = {(0, 0): ((5.599999999999999, 6.400000000000002, 0.0), 160),
+             (150, 84): ((0.6859999999999998, 1.5680000000000005, 4.5), 148),
+             (40, 100): ((4.0488, 4.614400000000001, 1.0), 284),
+             (299, 167): ((5.398399999999999, 6.0672000000000015, 0.0), 168)}
+    for (x, y), (rgb, words) in table.items():
+        got, w = oracle.rtiow_pixel(world.desc, cam.c, x, y)
+        assert tuple(got) == rgb, (x, y, got)
+        assert w == words
+
+
+def test_rtc_golden_obj_scene_byte_exact(rl, oracle, golden):
+    expected = golden("test_obj_scene.ppm.gz")
+    assert hashlib.md5(expected).hexdigest() == "b7cd3f2c113c4c140211c51dee883c82"
+    world = rl.RtcWorld.test_obj_scene(golden("teapot-low.obj"), 300, 200)
+    img = oracle.rtc_render(world.desc, world.camera, aa=1)
+    ppm = rl.canvas_ppm(img)
+    assert ppm.encode() == expected
+    lit = int((img.reshape(-1, 3).max(axis=1) > 0).sum())
+    assert lit == 19233
