@@ -1,0 +1,120 @@
+// Internal (not part of the ABI): the device-side scene layout.
+//
+// rl_*_scene_create "compiles" the caller's object graph (rl_href / rl_oref trees) into a THREADED
+// PROGRAM: ops laid out in the reference's depth-first evaluation order, every box op carrying the
+// pc to jump to when its test fails.  Traversal is then `pc = hit ? pc + 1 : skip` — no per-lane
+// stack at all — and visits nodes and primitives in exactly the order of the reference's recursive
+// Hittable::hit / Object::intersect, so closest-hit tie-breaking ("later wins") and every AABB test's
+// ray_t.max are identical to the reference (bvh.rs:79-95, hittable/mod.rs:88-105).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rl_render.h"
+
+namespace rl {
+
+// ---------------------------------------------------------------- RTIOW
+enum : uint32_t {
+  OP_END = 0,
+  OP_BOX = 1,        // AABB test; miss -> pc = skip
+  OP_BOX_SPH = 2,    // BVH leaf of 1-2 spheres (a, b; b = NONE if single): AABB test then the spheres; next = skip
+  OP_SPHERE = 3,     // sphere a
+  OP_PLANAR = 4,     // planar a
+  OP_BOX_PLANAR = 5, // BVH leaf of 1-2 planars
+  OP_PUSH_TRANSLATE = 6,
+  OP_POP_TRANSLATE = 7,
+  OP_PUSH_TRANSFORM = 8,
+  OP_POP_TRANSFORM = 9,
+};
+static const uint32_t NONE = 0xFFFFFFFFu;
+static const uint32_t SPH_MOVING = 0x80000000u;  // flag bit in a sphere index payload
+
+struct alignas(16) DevOp {  // 64 B
+  double box[6];            // x.min,x.max,y.min,y.max,z.min,z.max
+  uint32_t code, skip, a, b;
+};
+static_assert(sizeof(DevOp) == 64, "DevOp must be 64 B");
+
+struct alignas(16) DevSphere {  // 64 B
+  double c0[3];
+  double dc[3];   // center1 - center0 (sphere.rs:27: p2 - p1), 0 when stationary
+  double r2;      // radius * radius   (sphere.rs:40)
+  double inv_r;   // 1.0 / radius      (vec3.rs:177-179 via sphere.rs:62)
+};
+static_assert(sizeof(DevSphere) == 64, "DevSphere must be 64 B");
+
+struct alignas(16) DevPlanar {  // 128 B core (plane.rs:12-20) + optional per-vertex data
+  double q[3], u[3], v[3], w[3], normal[3];
+  double d;
+  uint32_t kind, material, has_normals, has_uvs;
+  double normals[9];
+  double uvs[6];
+  double pad;
+};
+
+struct DevMaterial {  // 48 B
+  uint32_t kind, texture;
+  double albedo[3];
+  double fuzz, ior;
+};
+struct DevTexture {  // 48 B
+  uint32_t kind, even, odd, image;
+  double color[3];
+  double inv_scale;
+};
+struct DevImage {
+  uint32_t width, height;
+  uint64_t offset;  // float offset into the image pool
+};
+
+struct RtiowProgram {
+  std::vector<DevOp> ops;
+  std::vector<DevSphere> spheres;
+  std::vector<uint32_t> sphere_material;
+  std::vector<DevPlanar> planars;
+  std::vector<rl_translate> translates;
+  std::vector<rl_transform> transforms;
+  std::vector<DevMaterial> materials;
+  std::vector<DevTexture> textures;
+  std::vector<DevImage> images;
+  std::vector<float> image_pool;
+  bool has_planars = false, has_instances = false, has_images = false;
+  uint32_t max_instance_depth = 0;
+};
+
+// Returns RL_OK or RL_E_INVALID (err filled).
+int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &out, std::string &err);
+
+// ---------------------------------------------------------------- RTC
+enum : uint32_t {
+  ROP_END = 0,
+  ROP_ENTER = 1,   // Transformed: a = transformed index
+  ROP_EXIT = 2,    // a = transformed index
+  ROP_BOUNDS = 3,  // Bounded: box test (tmin <= tmax); miss -> pc = skip
+  ROP_TRIS = 4,    // triangles [a, a+b)
+};
+
+struct alignas(16) DevTri {  // 160 B
+  double p1[3], e1[3], e2[3];
+  double n1[3], n2[3], n3[3];
+  uint32_t smooth, material;
+  double pad;
+};
+static_assert(sizeof(DevTri) == 160, "DevTri must be 160 B");
+
+struct RtcProgram {
+  std::vector<DevOp> ops;
+  std::vector<DevTri> tris;
+  std::vector<rl_rtc_transformed> xforms;
+  std::vector<rl_rtc_material> materials;
+  std::vector<rl_rtc_light> lights;
+  uint32_t max_reflection_depth = 5;
+  double void_color[3] = {0, 0, 0};
+  uint32_t max_xform_depth = 0;
+  bool needs_secondary = false;  // any reflective / transparent material
+};
+int compile_rtc(const rl_rtc_scene_desc &d, RtcProgram &out, std::string &err);
+
+}  // namespace rl

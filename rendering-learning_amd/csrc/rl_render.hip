@@ -1,0 +1,403 @@
+// rl_render.hip — the C ABI of include/rl_render.h over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+// No CPU fallback: every compute entry point fails with RL_E_NO_DEVICE unless rl_init succeeded on a GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rl_program.h"
+#include "rl_rtc_kernel.h"
+#include "rl_rtiow_kernel.h"
+
+using namespace rl;
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+bool g_ready = false;
+int g_device = -1;
+int g_cus = 0;
+size_t g_lds_max = 65536;
+hipStream_t g_stream = nullptr;  // library-owned stream for the host-buffer entry points
+
+int set_err(int code, const std::string &m) {
+  g_err = m;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return set_err(RL_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+int upload(const std::vector<T> &v, T **out) {
+  *out = nullptr;
+  size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+  HIP_TRY(hipMalloc((void **)out, bytes));
+  if (!v.empty()) HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RL_OK;
+}
+
+}  // namespace
+
+struct rl_scene {
+  int kind;  // 1 = RTIOW, 2 = RTC
+  // RTIOW
+  RtiowProgram rt;
+  DevOp *d_ops = nullptr;
+  DevSphere *d_spheres = nullptr;
+  uint32_t *d_sphere_material = nullptr;
+  DevPlanar *d_planars = nullptr;
+  rl_translate *d_translates = nullptr;
+  rl_transform *d_transforms = nullptr;
+  DevMaterial *d_materials = nullptr;
+  DevTexture *d_textures = nullptr;
+  DevImage *d_images = nullptr;
+  float *d_image_pool = nullptr;
+  // RTC
+  RtcProgram rc;
+  DevTri *d_tris = nullptr;
+  rl_rtc_transformed *d_xforms = nullptr;
+  rl_rtc_material *d_rmaterials = nullptr;
+  rl_rtc_light *d_lights = nullptr;
+  // per-scene scratch: [0] work counter (u32), [8..] 8 x u64 stats
+  unsigned char *d_scratch = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int rl_abi_version(void) { return RL_ABI_VERSION; }
+const char *rl_last_error(void) { return g_err.c_str(); }
+
+int rl_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return set_err(RL_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device >= 0) {
+    if (device >= n) return set_err(RL_E_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+  }
+  HIP_TRY(hipGetDevice(&g_device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_err(RL_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  g_cus = prop.multiProcessorCount;
+  g_lds_max = prop.sharedMemPerBlock > 65536 ? prop.sharedMemPerBlock : 65536;
+  if (prop.maxSharedMemoryPerMultiProcessor > g_lds_max) g_lds_max = prop.maxSharedMemoryPerMultiProcessor;
+  if (g_lds_max > 163840) g_lds_max = 163840;
+  if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_ready = true;
+  return RL_OK;
+}
+
+void rl_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_stream) hipStreamDestroy(g_stream);
+  g_stream = nullptr;
+  g_ready = false;
+}
+
+int rl_device_info(char *name, int cap) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  if (name && cap > 0) {
+    std::strncpy(name, prop.gcnArchName, (size_t)cap - 1);
+    name[cap - 1] = 0;
+  }
+  return prop.multiProcessorCount;
+}
+
+void rl_scene_destroy(rl_scene *s) {
+  if (!s) return;
+  hipFree(s->d_ops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
+  hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
+  hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  delete s;
+}
+
+static int scene_common(rl_scene *s) {
+  HIP_TRY(hipMalloc((void **)&s->d_scratch, 128));
+  HIP_TRY(hipMemset(s->d_scratch, 0, 128));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  return RL_OK;
+}
+
+rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
+  if (!g_ready) {
+    set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
+    return nullptr;
+  }
+  if (!desc) {
+    set_err(RL_E_INVALID, "null scene descriptor");
+    return nullptr;
+  }
+  rl_scene *s = new rl_scene();
+  s->kind = 1;
+  std::string err;
+  if (compile_rtiow(*desc, s->rt, err) != RL_OK) {
+    set_err(RL_E_INVALID, err);
+    delete s;
+    return nullptr;
+  }
+  if (s->rt.has_planars || s->rt.has_instances) {
+    set_err(RL_E_UNSUPPORTED, "planar primitives / instances have no gfx950 kernel yet in this build");
+    delete s;
+    return nullptr;
+  }
+  // spheres do not carry UVs on the device (sphere.rs:91-99 is consumed only by Image textures)
+  for (size_t i = 0; i < s->rt.spheres.size(); i++) {
+    const DevMaterial &m = s->rt.materials[s->rt.sphere_material[i]];
+    if (m.kind != RL_MAT_LAMBERTIAN && m.kind != RL_MAT_DIFFUSE_LIGHT) continue;
+    std::vector<uint32_t> st{m.texture};
+    size_t visited = 0;
+    while (!st.empty() && visited++ < 100000) {
+      const DevTexture &t = s->rt.textures[st.back()];
+      st.pop_back();
+      if (t.kind == RL_TEX_IMAGE) {
+        set_err(RL_E_UNSUPPORTED, "Image texture on a sphere (needs sphere UVs) is not supported");
+        delete s;
+        return nullptr;
+      }
+      if (t.kind == RL_TEX_CHECKER) st.push_back(t.even), st.push_back(t.odd);
+    }
+  }
+  int rc = RL_OK;
+  if ((rc = upload(s->rt.ops, &s->d_ops)) || (rc = upload(s->rt.spheres, &s->d_spheres)) || (rc = upload(s->rt.sphere_material, &s->d_sphere_material)) ||
+      (rc = upload(s->rt.planars, &s->d_planars)) || (rc = upload(s->rt.translates, &s->d_translates)) || (rc = upload(s->rt.transforms, &s->d_transforms)) ||
+      (rc = upload(s->rt.materials, &s->d_materials)) || (rc = upload(s->rt.textures, &s->d_textures)) || (rc = upload(s->rt.images, &s->d_images)) ||
+      (rc = upload(s->rt.image_pool, &s->d_image_pool)) || (rc = scene_common(s))) {
+    rl_scene_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+// ChaCha8Rng::seed_from_u64 (rand_core 0.6.4): PCG32 expands the u64 into the 256-bit key
+static void chacha_key_from_seed(uint64_t state, uint32_t key[8]) {
+  const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+  for (int k = 0; k < 8; k++) {
+    state = state * MUL + INC;
+    uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+    uint32_t rot = (uint32_t)(state >> 59);
+    key[k] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+  }
+}
+
+static void read_stats(const unsigned long long *h, float ms, rl_stats *st) {
+  st->rays = h[0], st->node_tests = h[1], st->sphere_tests = h[2], st->planar_tests = h[3];
+  st->instance_enters = h[4], st->rng_words = h[5], st->flagged = h[6];
+  st->kernel_ms = ms;
+}
+
+int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step,
+                           void *d_out, void *hip_stream, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || scene->kind != 1 || !cam || !d_out || row_step == 0) return set_err(RL_E_INVALID, "bad argument");
+  if (cam->image_width == 0 || cam->image_height == 0) return set_err(RL_E_INVALID, "empty image");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  uint32_t H = cam->image_height, W = cam->image_width;
+  uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
+  if (nrows == 0) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
+  }
+  RtiowParams P{};
+  P.ops = scene->d_ops, P.spheres = scene->d_spheres, P.sphere_material = scene->d_sphere_material;
+  P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
+  P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool;
+  P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
+  P.cam = *cam;
+  chacha_key_from_seed(cam->seed, P.key);
+  P.first_sample = first_sample;
+  P.row_first = row_first, P.row_step = row_step, P.nrows = nrows;
+  P.tiles_x = (W + 7) / 8;
+  uint64_t slots = (uint64_t)P.tiles_x * ((nrows + 7) / 8) * 64ull;
+  if (slots >= 0xFFFF0000ull) return set_err(RL_E_INVALID, "image too large");
+  P.n_slots = (uint32_t)slots;
+  P.work_counter = (uint32_t *)scene->d_scratch;
+  P.stats = (unsigned long long *)(scene->d_scratch + 64);
+  P.out = (double *)d_out;
+
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 128, stream));
+  constexpr int NT = 1024;
+  size_t rng_bytes = (size_t)8 * NT * sizeof(unsigned long long);
+  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
+  bool lds_scene = rng_bytes + scene_bytes <= g_lds_max;
+  size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
+  uint32_t blocks = (uint32_t)((slots + NT - 1) / NT);
+  if (blocks > (uint32_t)g_cus) blocks = (uint32_t)g_cus;  // one 1024-thread workgroup per CU, persistent lanes
+  bool want_stats = st != nullptr;
+  auto launch = [&](auto kern) -> int {
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, stream, P);
+    HIP_TRY(hipGetLastError());
+    if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
+    return RL_OK;
+  };
+  int rc;
+  if (lds_scene) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>) : launch(rtiow_spheres_kernel<NT, true, false>);
+  else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>) : launch(rtiow_spheres_kernel<NT, false, false>);
+  if (rc != RL_OK) return rc;
+  if (want_stats) {
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, P.stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+    read_stats(h, ms, st);
+    if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
+  }
+  return RL_OK;
+}
+
+int rl_rtiow_render_rows(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step,
+                         double *out, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || !cam || !out || row_step == 0) return set_err(RL_E_INVALID, "bad argument");
+  uint32_t H = cam->image_height, W = cam->image_width;
+  uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
+  size_t bytes = (size_t)nrows * W * 3 * sizeof(double);
+  if (bytes == 0) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
+  }
+  double *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_out, bytes));
+  rl_stats local;
+  int rc = rl_rtiow_render_device(scene, cam, first_sample, row_first, row_step, d_out, g_stream, &local);
+  if (rc == RL_OK || rc == RL_E_DEGENERATE) {
+    hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+  }
+  hipFree(d_out);
+  if (st) *st = local;
+  return rc;
+}
+
+int rl_rtiow_render(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, double *out, rl_stats *st) {
+  return rl_rtiow_render_rows(scene, cam, first_sample, 0, 1, out, st);
+}
+
+// ------------------------------------------------------------------ RTC
+rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
+  if (!g_ready) {
+    set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
+    return nullptr;
+  }
+  if (!desc) {
+    set_err(RL_E_INVALID, "null scene descriptor");
+    return nullptr;
+  }
+  rl_scene *s = new rl_scene();
+  s->kind = 2;
+  std::string err;
+  if (compile_rtc(*desc, s->rc, err) != RL_OK) {
+    set_err(RL_E_INVALID, err);
+    delete s;
+    return nullptr;
+  }
+  if (s->rc.needs_secondary) {
+    set_err(RL_E_UNSUPPORTED, "reflective / transparent materials (recursive color_at) have no gfx950 kernel yet in this build");
+    delete s;
+    return nullptr;
+  }
+  int rc = RL_OK;
+  if ((rc = upload(s->rc.ops, &s->d_ops)) || (rc = upload(s->rc.tris, &s->d_tris)) || (rc = upload(s->rc.xforms, &s->d_xforms)) ||
+      (rc = upload(s->rc.materials, &s->d_rmaterials)) || (rc = upload(s->rc.lights, &s->d_lights)) || (rc = scene_common(s))) {
+    rl_scene_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out,
+                         void *hip_stream, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || scene->kind != 2 || !cam || !d_out || row_step == 0 || aa == 0) return set_err(RL_E_INVALID, "bad argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return set_err(RL_E_INVALID, "empty image");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  uint32_t H = cam->vsize, W = cam->hsize;
+  uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
+  if (nrows == 0) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
+  }
+  RtcParams P{};
+  P.ops = scene->d_ops, P.tris = scene->d_tris, P.xforms = scene->d_xforms, P.materials = scene->d_rmaterials, P.lights = scene->d_lights;
+  P.n_ops = (uint32_t)scene->rc.ops.size(), P.n_tris = (uint32_t)scene->rc.tris.size();
+  P.n_xforms = (uint32_t)scene->rc.xforms.size(), P.n_lights = (uint32_t)scene->rc.lights.size();
+  P.cam = *cam;
+  P.aa = aa;
+  P.row_first = row_first, P.row_step = row_step, P.nrows = nrows;
+  std::memcpy(P.void_color, scene->rc.void_color, 24);
+  P.out = (double *)d_out;
+  P.stats = (unsigned long long *)(scene->d_scratch + 64);
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 128, stream));
+  constexpr int NT = 256;
+  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_tris * sizeof(DevTri);
+  bool lds_scene = scene_bytes <= 65536;
+  size_t lds = lds_scene ? scene_bytes : 0;
+  uint64_t total = (uint64_t)W * nrows;
+  uint64_t want = (total + NT - 1) / NT;
+  uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
+  bool want_stats = st != nullptr;
+  if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
+  if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
+  else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
+  HIP_TRY(hipGetLastError());
+  if (want_stats) {
+    HIP_TRY(hipEventRecord(scene->ev1, stream));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, P.stats, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+    read_stats(h, ms, st);
+    if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
+  }
+  return RL_OK;
+}
+
+int rl_rtc_render_rows(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, double *out,
+                       rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || !cam || !out || row_step == 0) return set_err(RL_E_INVALID, "bad argument");
+  uint32_t H = cam->vsize, W = cam->hsize;
+  uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
+  size_t bytes = (size_t)nrows * W * 3 * sizeof(double);
+  if (bytes == 0) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
+  }
+  double *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_out, bytes));
+  rl_stats local;
+  int rc = rl_rtc_render_device(scene, cam, aa, row_first, row_step, d_out, g_stream, &local);
+  if (rc == RL_OK || rc == RL_E_DEGENERATE) {
+    hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+  }
+  hipFree(d_out);
+  if (st) *st = local;
+  return rc;
+}
+
+int rl_rtc_render(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, double *out, rl_stats *st) {
+  return rl_rtc_render_rows(scene, cam, aa, 0, 1, out, st);
+}
+
+}  // extern "C"
