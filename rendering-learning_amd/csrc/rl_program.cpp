@@ -73,13 +73,16 @@ struct RtiowCompiler {
         uint32_t idx = (uint32_t)p.ops.size();
         DevOp op{};
         std::memcpy(op.box, n.bbox, sizeof op.box);
+        uint32_t finite = BOX_FINITE;  // every bound finite and small enough for the filtered (reciprocal) AABB test
+        for (int k = 0; k < 6; k++)
+          if (!(std::fabs(n.bbox[k]) <= 1e100)) finite = 0;
         bool all_sph = true, all_pl = true;
         for (uint32_t i = 0; i < n.n_children; i++) {
           all_sph &= n.child[i].kind == RL_H_SPHERE;
           all_pl &= n.child[i].kind == RL_H_PLANAR;
         }
         if (all_sph) {
-          op.code = OP_BOX_SPH;
+          op.code = OP_BOX_SPH | finite;
           op.a = sphere_payload(n.child[0].index);
           op.b = n.n_children == 2 ? sphere_payload(n.child[1].index) : NONE;
           op.skip = idx + 1;
@@ -87,7 +90,7 @@ struct RtiowCompiler {
           return true;
         }
         if (all_pl) {
-          op.code = OP_BOX_PLANAR;
+          op.code = OP_BOX_PLANAR | finite;
           op.a = n.child[0].index;
           op.b = n.n_children == 2 ? n.child[1].index : NONE;
           op.skip = idx + 1;
@@ -95,7 +98,7 @@ struct RtiowCompiler {
           p.has_planars = true;
           return true;
         }
-        op.code = OP_BOX, op.a = op.b = NONE;
+        op.code = OP_BOX | finite, op.a = op.b = NONE;
         p.ops.push_back(op);
         bvh_busy[h.index] = 1;
         for (uint32_t i = 0; i < n.n_children; i++)

@@ -28,6 +28,7 @@ enum : uint32_t {
   OP_PUSH_TRANSFORM = 8,
   OP_POP_TRANSFORM = 9,
 };
+static const uint32_t BOX_FINITE = 0x100u;  // flag OR-ed into a box op's code: all six bounds finite, |b| <= 1e100
 static const uint32_t NONE = 0xFFFFFFFFu;
 static const uint32_t SPH_MOVING = 0x80000000u;  // flag bit in a sphere index payload
 

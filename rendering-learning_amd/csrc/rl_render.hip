@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -12,6 +13,7 @@
 #include "rl_program.h"
 #include "rl_rtc_kernel.h"
 #include "rl_rtiow_kernel.h"
+#include "rl_rtiow_wave.h"
 
 using namespace rl;
 
@@ -24,6 +26,7 @@ int g_device = -1;
 int g_cus = 0;
 size_t g_lds_max = 65536;
 hipStream_t g_stream = nullptr;  // library-owned stream for the host-buffer entry points
+int g_rtiow_variant = 0;         // 0 = automatic; see RL_RTIOW_KERNEL in rl_rtiow_render_device
 
 int set_err(int code, const std::string &m) {
   g_err = m;
@@ -95,6 +98,10 @@ int rl_init(int device) {
   if (prop.maxSharedMemoryPerMultiProcessor > g_lds_max) g_lds_max = prop.maxSharedMemoryPerMultiProcessor;
   if (g_lds_max > 163840) g_lds_max = 163840;
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
+    std::string sv(v);
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+  }
   g_ready = true;
   return RL_OK;
 }
@@ -128,8 +135,8 @@ void rl_scene_destroy(rl_scene *s) {
 }
 
 static int scene_common(rl_scene *s) {
-  HIP_TRY(hipMalloc((void **)&s->d_scratch, 128));
-  HIP_TRY(hipMemset(s->d_scratch, 0, 128));
+  HIP_TRY(hipMalloc((void **)&s->d_scratch, 512));
+  HIP_TRY(hipMemset(s->d_scratch, 0, 512));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   return RL_OK;
@@ -230,27 +237,55 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.work_counter = (uint32_t *)scene->d_scratch;
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   P.out = (double *)d_out;
+  P.tune[0] = 16, P.tune[1] = 6;
+  if (const char *t = std::getenv("RL_TUNE")) {  // "iters,floor16" (A/B only)
+    unsigned a = 16, b = 12;
+    if (std::sscanf(t, "%u,%u", &a, &b) == 2) P.tune[0] = a, P.tune[1] = b;
+  }
 
-  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 128, stream));
-  constexpr int NT = 1024;
-  size_t rng_bytes = (size_t)8 * NT * sizeof(unsigned long long);
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
-  bool lds_scene = rng_bytes + scene_bytes <= g_lds_max;
-  size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
-  uint32_t blocks = (uint32_t)((slots + NT - 1) / NT);
-  if (blocks > (uint32_t)g_cus) blocks = (uint32_t)g_cus;  // one 1024-thread workgroup per CU, persistent lanes
   bool want_stats = st != nullptr;
-  auto launch = [&](auto kern) -> int {
+  auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
+    size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
+    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
+    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));  // persistent lanes: as many workgroups as stay resident
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nt > 2048) per_cu = 2048 / nt;
+    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, stream, P);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
     HIP_TRY(hipGetLastError());
     if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
     return RL_OK;
   };
+  // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
+  // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
+  int variant = g_rtiow_variant;
+  if (variant == 0) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
+    auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
+    variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
+  }
   int rc;
-  if (lds_scene) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>) : launch(rtiow_spheres_kernel<NT, true, false>);
-  else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>) : launch(rtiow_spheres_kernel<NT, false, false>);
+#define RL_LAUNCH_WAVE(NT)                                                                                              \
+  {                                                                                                                     \
+    size_t rb = (size_t)16 * NT * sizeof(unsigned long long);                                                           \
+    bool in_lds = rb + scene_bytes <= g_lds_max;                                                                        \
+    if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, true, false>, NT, rb, true); \
+    else rc = want_stats ? launch(rtiow_wave_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, false, false>, NT, rb, false);   \
+  }
+  if (variant == 1) {
+    constexpr int NT = 1024;
+    size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
+    bool in_lds = rb + scene_bytes <= g_lds_max;
+    if (in_lds) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_spheres_kernel<NT, true, false>, NT, rb, true);
+    else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_spheres_kernel<NT, false, false>, NT, rb, false);
+  } else if (variant == 768) RL_LAUNCH_WAVE(768)
+  else if (variant == 1024) RL_LAUNCH_WAVE(1024)
+  else if (variant == 256) RL_LAUNCH_WAVE(256)
+  else RL_LAUNCH_WAVE(512)
+#undef RL_LAUNCH_WAVE
   if (rc != RL_OK) return rc;
   if (want_stats) {
     unsigned long long h[8];
@@ -261,6 +296,13 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     read_stats(h, ms, st);
     if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
   }
+  return RL_OK;
+}
+
+// Not part of the ABI (tools only): scheduler occupancy counters of the last STATS launch, 32 x u64.
+int rl_debug_sched(const rl_scene *scene, unsigned long long *out32) {
+  if (!scene || !out32) return RL_E_INVALID;
+  HIP_TRY(hipMemcpy(out32, scene->d_scratch + 128, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RL_OK;
 }
 
@@ -346,7 +388,7 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
   std::memcpy(P.void_color, scene->rc.void_color, 24);
   P.out = (double *)d_out;
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
-  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 128, stream));
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   constexpr int NT = 256;
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_tris * sizeof(DevTri);
   bool lds_scene = scene_bytes <= 65536;

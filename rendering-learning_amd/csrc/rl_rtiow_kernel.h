@@ -31,6 +31,7 @@ struct RtiowParams {
   uint32_t tiles_x, n_slots;
   uint32_t *work_counter;
   double *out;
+  uint32_t tune[4];           // wave kernel: [0] max TRAV steps per scheduling round, [1] leave-TRAV population floor in 1/16ths
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
 };
 
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(NT) rtiow_spheres_kernel(RtiowParams P) {
         uint32_t pc = 0;
         for (;;) {
           const DevOp &op = ops[pc];
-          uint32_t code = op.code;
+          uint32_t code = op.code & 0xFFu;
           if (code == OP_END) break;
           if (code == OP_SPHERE) {
             if (STATS) cnt.spheres++;

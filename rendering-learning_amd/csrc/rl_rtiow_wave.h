@@ -1,0 +1,409 @@
+// RTIOW sphere/BVH kernel, wave-scheduled form ("v2").
+//
+// Same arithmetic and same per-pixel / per-sample / per-ray order as rl_rtiow_kernel.h (and as the
+// reference), different *schedule*: each lane is a small state machine
+//     GEN  (claim pixel / start next sample: new ChaCha stream, camera ray)
+//     TRAV (ONE box op of the threaded scene program per step)
+//     LEAF (the 1-2 Sphere::hit tests of a BVH leaf whose box passed)
+//     FILL (top the lane's ChaCha ring up by one block)
+//     SHADE(miss -> background; hit -> rebuild HitRecord, scatter, next ray)
+// and the 64-wide wave repeatedly runs the state that has the most lanes waiting in it.  A lane
+// whose path ends starts its pixel's next sample at once (path regeneration; legal because the
+// per-pixel sample order is preserved), so no lane idles while another finishes a long path, and
+// ChaCha block generation always runs for many lanes at once instead of lane-by-lane inside
+// rejection loops.
+//
+// AABB test: the reference divides six times per box ((min-o)/d, (max-o)/d per axis, aabb.rs:143-152).
+// Here each ray carries inv = 1.0/d (three IEEE divisions per ray) and oi = o*inv, and a box test uses
+// t'' = fma(b, inv, -oi), one instruction per bound.  The DECISION tmin < tmax is taken from the
+// approximations only when |tmax''-tmin''| exceeds a rigorous error margin (see RayAux); otherwise — and for non-finite boxes or rays with a zero / tiny / huge
+// direction component — the lane re-evaluates the reference's exact divisions.  Decisions are
+// therefore bit-identical to the reference (tests assert equal AABB/sphere/ray/RNG-word counters).
+#pragma once
+#include "rl_rtiow_kernel.h"
+
+namespace rl {
+
+enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5 };
+
+// two-block ChaCha ring in LDS: 16 u64 slots per lane, slot-major ([slot][lane]) => conflict-free
+template <int NT>
+struct Ring {
+  const uint32_t *key;
+  unsigned long long *s_rng;  // [16][NT]
+  int tid;
+  uint64_t stream;
+  uint32_t pos;     // u32 word position within the pixel
+  uint32_t blk_lo;  // lowest resident block counter
+  uint32_t nres;    // resident blocks: blk_lo .. blk_lo+nres-1 (0..2); block c lives in half (c & 1)
+
+  __device__ __forceinline__ void gen_block(uint32_t c) { chacha8_block_to_lds<NT>(key, c, stream, s_rng + (size_t)(c & 1u) * 8 * NT, tid); }
+  __device__ __forceinline__ void reset_stream(uint64_t s) {  // set_stream keeps pos; both resident blocks become stale
+    stream = s;
+    blk_lo = pos >> 4;
+    gen_block(blk_lo);
+    gen_block(blk_lo + 1);
+    nres = 2;
+  }
+  __device__ __forceinline__ bool low() const { return (pos >> 4) >= blk_lo + nres - 1u; }  // reading from the newest block
+  __device__ __forceinline__ void top_up() {  // make block (newest+1) resident, dropping the oldest
+    uint32_t c = blk_lo + nres;
+    gen_block(c);
+    if (nres == 2) blk_lo++;
+    else nres++;
+  }
+  __device__ __forceinline__ uint64_t next_u64() {
+    uint32_t c = pos >> 4;
+    if (c - blk_lo >= nres) top_up();  // rare inline path (long rejection streaks)
+    uint64_t v = s_rng[((size_t)(c & 1u) * 8 + ((pos & 15u) >> 1)) * NT + tid];
+    pos += 2;
+    return v;
+  }
+  __device__ __forceinline__ double gen_f64() { return (double)(next_u64() >> 11) * 0x1.0p-53; }
+  __device__ __forceinline__ double uniform_m1_1() {
+    double v = __longlong_as_double((long long)((next_u64() >> 12) | 0x3FF0000000000000ull));
+    return (v - 1.0) * 2.0 + (-1.0);
+  }
+  __device__ __forceinline__ D3 unit_sphere() {
+    for (;;) {
+      double x1 = uniform_m1_1(), x2 = uniform_m1_1();
+      double s = x1 * x1 + x2 * x2;
+      if (s >= 1.0) continue;
+      double f = 2.0 * sqrt(1.0 - s);
+      return D3{x1 * f, x2 * f, 1.0 - 2.0 * s};
+    }
+  }
+  __device__ __forceinline__ void unit_disc(double &a, double &b) {
+    for (;;) {
+      a = uniform_m1_1();
+      b = uniform_m1_1();
+      if (a * a + b * b <= 1.0) return;
+    }
+  }
+};
+
+// per-ray reciprocal + eligibility for the filtered AABB test
+__device__ __forceinline__ bool ray_fast_ok(D3 o, D3 d) {
+  auto okd = [](double v) { double a = fabs(v); return a >= 1e-100 && a <= 1e100; };
+  auto oko = [](double v) { return fabs(v) <= 1e100; };
+  return okd(d.x) && okd(d.y) && okd(d.z) && oko(o.x) && oko(o.y) && oko(o.z);
+}
+
+// Per-ray constants of the filtered AABB test.
+//   inv = 1/d (IEEE), oi = o*inv, slack = 4u * max|oi|.
+// A box test evaluates t'' = fma(b, inv, -oi) ~ (b-o)/d with ONE instruction per bound.  Against the
+// reference's q^ = RN(RN(b-o)/d):  |t'' - q^| <= 4.1u|t''| + 1.1u|oi|  (u = 2^-53; three roundings in
+// t'', two in q^, plus the cancellation term of b*inv - o*inv).  min/max commute with the relative part
+// and are 1-Lipschitz in the absolute part, so |tmin'' - tmin| <= 4.2u|tmin''| + 1.1u max|oi| and the
+// same for tmax: the decision is certain whenever |tmax''-tmin''| > 8u(|tmin''|+|tmax''|) + slack.
+struct RayAux {
+  D3 inv, oi;
+  double slack;
+  bool fast_ok;
+};
+__device__ __forceinline__ RayAux ray_aux(D3 o, D3 d) {
+  RayAux a;
+  a.inv = d3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  a.oi = d3(o.x * a.inv.x, o.y * a.inv.y, o.z * a.inv.z);
+  a.slack = fmax(fmax(fabs(a.oi.x), fabs(a.oi.y)), fabs(a.oi.z)) * 4.4408920985006262e-16;  // 4u
+  a.fast_ok = ray_fast_ok(o, d);
+  return a;
+}
+
+// Filtered AABB::hit. tmin_ is the kernel constant 1e-10 (> 0), tmax_ the closest hit so far.
+// `certain` = false: the caller must evaluate the reference's divisions (aabb_hit).
+__device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, double tmax_, bool &certain) {
+  const double tmin_ = 1e-10;
+  double t0x = fma(b[0], ra.inv.x, -ra.oi.x), t1x = fma(b[1], ra.inv.x, -ra.oi.x);
+  double t0y = fma(b[2], ra.inv.y, -ra.oi.y), t1y = fma(b[3], ra.inv.y, -ra.oi.y);
+  double t0z = fma(b[4], ra.inv.z, -ra.oi.z), t1z = fma(b[5], ra.inv.z, -ra.oi.z);
+  double tmin = fmax(fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z)), tmin_);
+  double tmax = fmin(fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z)), tmax_);
+  double diff = tmax - tmin;
+  double thresh = fma(tmin + fabs(tmax), 8.8817841970012523e-16, ra.slack);  // 8u(|tmin|+|tmax|) + slack
+  certain = fabs(diff) > thresh;                                            // false also for NaN / inf arithmetic
+  return diff > 0.0;
+}
+
+template <int NT, bool LDS_SCENE, bool STATS>
+__global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  unsigned long long *s_rng = (unsigned long long *)smem;  // [16][NT]
+  const DevOp *ops = P.ops;
+  const DevSphere *spheres = P.spheres;
+  if (LDS_SCENE) {
+    DevOp *s_ops = (DevOp *)(smem + (size_t)16 * NT * sizeof(unsigned long long));
+    DevSphere *s_sph = (DevSphere *)(s_ops + P.n_ops);
+    const uint4 *g = (const uint4 *)P.ops;
+    uint4 *l = (uint4 *)s_ops;
+    for (uint32_t i = tid; i < P.n_ops * 4u; i += NT) l[i] = g[i];
+    g = (const uint4 *)P.spheres;
+    l = (uint4 *)s_sph;
+    for (uint32_t i = tid; i < P.n_spheres * 4u; i += NT) l[i] = g[i];
+    __syncthreads();
+    ops = s_ops;
+    spheres = s_sph;
+  }
+  const rl_rtiow_camera &cam = P.cam;
+  const uint32_t W = cam.image_width;
+  const uint32_t spp = cam.samples_per_pixel;
+  const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+
+  // ---- per-lane persistent state
+  Ring<NT> rng{P.key, s_rng, tid, 0ull, 0u, 0u, 0u};
+  uint32_t state = ST_GEN;
+  uint32_t px = 0, pr = 0, n = spp;  // n == spp: no pixel owned yet
+  bool have_pixel = false;
+  D3 sum = d3(0.0, 0.0, 0.0);
+  D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), thr = d3(1.0, 1.0, 1.0);
+  RayAux ra = ray_aux(o, d);
+  double time = 0.0, closest = INF;
+  uint32_t pc = 0, hit_prim = NONE, depth = 0;
+  uint32_t c_rays = 0, c_flag = 0;
+  unsigned long long c_nodes = 0, c_sph = 0, c_words = 0;
+
+  unsigned long long sc_exec[6] = {0, 0, 0, 0, 0, 0}, sc_pop[6] = {0, 0, 0, 0, 0, 0}, sc_cyc[6] = {0, 0, 0, 0, 0, 0};
+  for (;;) {
+    // ---- wave scheduler: run the state with the most lanes in it (ties -> TRAV, SHADE, FILL, GEN)
+    int n_trav = __popcll(__ballot(state == ST_TRAV));
+    int n_shade = __popcll(__ballot(state == ST_SHADE));
+    int n_fill = __popcll(__ballot(state == ST_FILL));
+    int n_gen = __popcll(__ballot(state == ST_GEN));
+    int n_leaf = __popcll(__ballot(state == ST_LEAF));
+    if ((n_trav | n_shade | n_fill | n_gen | n_leaf) == 0) break;
+    uint32_t pick = ST_TRAV;
+    int best = n_trav;
+    if (n_leaf > best) pick = ST_LEAF, best = n_leaf;
+    if (n_shade > best) pick = ST_SHADE, best = n_shade;
+    if (n_fill > best) pick = ST_FILL, best = n_fill;
+    if (n_gen > best) pick = ST_GEN, best = n_gen;
+
+    unsigned long long t_begin = 0;
+    if (STATS) {  // debug (tools/sched.py): block executions, lanes served and shader cycles per state, per wave
+      t_begin = __builtin_readcyclecounter();
+      if (pick != ST_TRAV) {
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (pick == (uint32_t)k) sc_exec[k]++, sc_pop[k] += (unsigned)best;
+      }
+    }
+    if (pick == ST_TRAV) {
+      // several steps per scheduling decision while the population stays near its starting size
+      int floor_n = (best * (int)P.tune[1]) >> 4;
+      for (int it = 0; it < (int)P.tune[0]; it++) {
+        if (STATS) {
+          int np = __popcll(__ballot(state == ST_TRAV));
+          sc_exec[ST_TRAV]++, sc_pop[ST_TRAV] += (unsigned)np;
+        }
+        if (state == ST_TRAV) {
+          // one LDS round trip: the whole 64-B op, then branch-free bookkeeping
+          const DevOp &op = ops[pc];
+          double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+          uint32_t code = op.code, skip = op.skip;
+          uint32_t kind = code & 0xFFu;
+          bool is_box = (kind == OP_BOX) | (kind == OP_BOX_SPH);
+          bool certain;
+          bool hitb = aabb_fast(bx, ra, closest, certain);
+          if (is_box && !(certain && ra.fast_ok && (code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, closest);  // rare: exact divisions
+          if (STATS) c_nodes += is_box ? 1u : 0u;
+          bool to_leaf = (kind == OP_SPHERE) | ((kind == OP_BOX_SPH) & hitb);  // pc stays: LEAF re-reads a, b
+          uint32_t npc = (is_box & !hitb) ? skip : ((kind == OP_BOX) ? pc + 1u : pc);
+          uint32_t nstate = (kind == OP_END) ? (rng.low() ? ST_FILL : ST_SHADE) : (to_leaf ? ST_LEAF : ST_TRAV);
+          pc = npc;
+          state = nstate;
+        }
+        if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
+      }
+    } else if (pick == ST_LEAF) {
+      if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
+        const DevOp &op = ops[pc];
+        uint32_t a = op.a, b = op.b;
+        Hit h{closest, hit_prim};
+        if (STATS) c_sph++;
+        if (sphere_hit(spheres[a & ~SPH_MOVING], a, o, d, time, 1e-10, h)) c_flag++;
+        if (b != NONE) {
+          if (STATS) c_sph++;
+          if (sphere_hit(spheres[b & ~SPH_MOVING], b, o, d, time, 1e-10, h)) c_flag++;
+        }
+        closest = h.t, hit_prim = h.prim;
+        pc = op.skip;
+        state = ST_TRAV;
+      }
+    } else if (pick == ST_FILL) {
+      if (state == ST_FILL) {
+        rng.top_up();
+        state = ST_SHADE;
+      }
+    } else if (pick == ST_GEN) {
+      if (state == ST_GEN) {
+        bool active = true;
+        if (n >= spp) {  // pixel finished (or none yet): write it out, claim the next slot
+          if (have_pixel) {
+            double *outp = P.out + ((size_t)pr * W + px) * 3;
+            outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+            if (STATS) c_words += rng.pos;
+            have_pixel = false;
+          }
+          uint32_t slot = wave_claim(P.work_counter);
+          if (slot >= P.n_slots) {
+            state = ST_DONE;
+            active = false;
+          } else {
+            uint32_t tile = slot >> 6, in = slot & 63u;
+            px = (tile % P.tiles_x) * 8u + (in & 7u);
+            pr = (tile / P.tiles_x) * 8u + (in >> 3);
+            if (px >= W || pr >= P.nrows) active = false;  // slot outside the image: stay in GEN, claim again next time
+            else {
+              have_pixel = true;
+              n = 0;
+              rng.pos = 0;
+              sum = d3(0.0, 0.0, 0.0);
+              if (spp == 0) active = false;
+            }
+          }
+        }
+        if (active) {
+          uint32_t y = P.row_first + pr * P.row_step;
+          uint64_t sample_index = (uint64_t)n + P.first_sample;
+          rng.reset_stream(sample_index * WH + (uint64_t)px * (uint64_t)W + (uint64_t)y);  // camera.rs:167-170
+          // get_ray camera.rs:203-216
+          D3 p00 = ld3(cam.pixel_00), du = ld3(cam.pixel_du), dv = ld3(cam.pixel_dv);
+          D3 pixel_center = (p00 + du * (double)px) + dv * (double)y;
+          double sx = -0.5 + rng.gen_f64();
+          double sy = -0.5 + rng.gen_f64();
+          D3 pixel_sample = pixel_center + (du * sx + dv * sy);
+          if (cam.defocus_angle <= 0.0) o = ld3(cam.lookfrom);
+          else {
+            double a, b;
+            rng.unit_disc(a, b);
+            o = (ld3(cam.lookfrom) + ld3(cam.defocus_disk_u) * a) + ld3(cam.defocus_disk_v) * b;
+          }
+          d = pixel_sample - o;
+          time = rng.gen_f64();
+          thr = d3(1.0, 1.0, 1.0);
+          depth = cam.max_depth;
+          if (depth == 0) {  // ray_color(depth 0) = black: the sample contributes (0,0,0)
+            sum = sum + d3(0.0, 0.0, 0.0);
+            n++;
+          } else {
+            c_rays++;
+            ra = ray_aux(o, d);
+            pc = 0, closest = INF, hit_prim = NONE;
+            state = ST_TRAV;
+          }
+        }
+      }
+    } else {  // ST_SHADE
+      if (state == ST_SHADE) {
+        bool path_done = false;
+        D3 nd = d;
+        D3 p = o;
+        if (hit_prim == NONE) {  // miss -> background (camera.rs:257)
+          sum = sum + thr * ld3(cam.background);
+          path_done = true;
+        } else {
+          uint32_t si = hit_prim & ~SPH_MOVING;
+          const DevSphere &s = spheres[si];
+          D3 c0 = ld3(s.c0);
+          D3 center = (hit_prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+          p = o + d * closest;
+          D3 outward = (p - center) * s.inv_r;
+          bool front = dot(d, outward) <= 0.0;
+          D3 normal = front ? outward : -outward;
+          const DevMaterial &m = P.materials[P.sphere_material[si]];
+          uint32_t kind = m.kind;
+          if (kind == RL_MAT_LAMBERTIAN) {
+            D3 dir = normal + rng.unit_sphere();
+            bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
+            nd = near_zero ? normal : dir;
+            thr = thr * texture_value(P, m.texture, 0.0, 0.0, p);
+          } else if (kind == RL_MAT_METAL) {
+            D3 reflected = d - normal * (2.0 * dot(d, normal));
+            nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
+            if (!(dot(nd, normal) > 0.0)) path_done = true;  // absorbed
+            else thr = thr * ld3(m.albedo);
+          } else if (kind == RL_MAT_DIELECTRIC) {
+            double ri = front ? 1.0 / m.ior : m.ior;
+            double m2 = len2(d);
+            D3 ud;
+            if (approx_eq_eps(m2, 0.0, 1e-16)) {
+              c_flag++;
+              ud = d;
+            } else
+              ud = normalize(d);
+            double cos_theta = fmin(dot(-ud, normal), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool reflect = ri * sin_theta > 1.0;
+            if (!reflect) {
+              double q = (1.0 - ri) / (1.0 + ri);
+              double r0 = q * q;
+              double xx = 1.0 - cos_theta;
+              double x2 = xx * xx;
+              double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
+              reflect = refl > rng.gen_f64();
+            }
+            if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
+            else {
+              D3 perp = (ud + normal * cos_theta) * ri;
+              D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
+              nd = perp + par;
+            }
+          } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
+            sum = sum + thr * texture_value(P, m.texture, 0.0, 0.0, p);
+            path_done = true;
+          } else {
+            path_done = true;  // Flat
+          }
+        }
+        if (!path_done) {
+          depth--;
+          if (depth == 0) path_done = true;  // ray_color(.., 0) = black
+        }
+        if (path_done) {
+          n++;
+          state = ST_GEN;
+        } else {
+          c_rays++;
+          o = p;
+          d = nd;
+          ra = ray_aux(o, d);
+          pc = 0, closest = INF, hit_prim = NONE;
+          state = ST_TRAV;
+        }
+      }
+    }
+    if (STATS) {
+      unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        if (pick == (uint32_t)k) sc_cyc[k] += dt;
+    }
+  }
+  if (STATS && (tid & 63) == 0) {
+    unsigned long long *sched = P.stats + 8;  // [3*s] executions, [3*s+1] lanes served, [3*s+2] cycles
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+      atomicAdd(&sched[3 * s], sc_exec[s]);
+      atomicAdd(&sched[3 * s + 1], sc_pop[s]);
+      atomicAdd(&sched[3 * s + 2], sc_cyc[s]);
+    }
+  }
+
+  unsigned long long v;
+  v = wave_sum((unsigned long long)c_rays);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[0], v);
+  v = wave_sum((unsigned long long)c_flag);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[6], v);
+  if (STATS) {
+    v = wave_sum(c_nodes);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[1], v);
+    v = wave_sum(c_sph);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[2], v);
+    v = wave_sum(c_words);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[5], v);
+  }
+}
+
+}  // namespace rl
