@@ -261,6 +261,16 @@ class World:
         return World(host_lib().rlh_rtiow_from_spheres(spheres.ctypes.data, len(spheres), materials.ctypes.data, len(materials),
                                                        textures.ctypes.data, len(textures), 1 if use_bvh else 0))
 
+    @staticmethod
+    def build(fn):
+        """Compose a world with the reference's scene-building vocabulary: fn(SceneBuilder) -> root object id."""
+        b = SceneBuilder()
+        try:
+            root = fn(b)
+            return World(host_lib().rlh_b_finish(b._b, root))
+        finally:
+            host_lib().rlh_builder_free(b._b)
+
     def device(self):
         """rl_rtiow_scene_create — uploads once, cached."""
         if self._device is None:
@@ -272,6 +282,122 @@ class World:
                 raise RLError(RL_E_INVALID, L.rl_last_error().decode())
             self._device = h
         return self._device
+
+
+class SceneBuilder:
+    """Thin handle over librl_host's builder: textures, materials and hittables by id (names follow the reference)."""
+
+    def __init__(self):
+        L = host_lib()
+        L.rlh_builder_new.restype = C.c_void_p
+        for n, a in (("rlh_builder_free", [C.c_void_p]), ("rlh_b_solid", [C.c_void_p, C.c_void_p]),
+                     ("rlh_b_checker", [C.c_void_p, C.c_double, C.c_int, C.c_int]),
+                     ("rlh_b_image", [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+                     ("rlh_b_material", [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_double, C.c_double]),
+                     ("rlh_b_sphere", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int]),
+                     ("rlh_b_planar", [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+                     ("rlh_b_triangle", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+                     ("rlh_b_translate", [C.c_void_p, C.c_int, C.c_void_p]),
+                     ("rlh_b_transform", [C.c_void_p, C.c_int, C.c_int, C.c_double]),
+                     ("rlh_b_group", [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
+                     ("rlh_b_obj", [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]),
+                     ("rlh_b_finish", [C.c_void_p, C.c_int])):
+            getattr(L, n).argtypes = a
+        L.rlh_b_finish.restype = C.c_void_p
+        self._L = L
+        self._b = L.rlh_builder_new()
+
+    @staticmethod
+    def _v(x):
+        return None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+
+    def _chk(self, r):
+        if r < 0:
+            raise RuntimeError("scene builder: " + self._L.rlh_last_error().decode())
+        return r
+
+    def solid(self, color):
+        c = self._v(color)
+        return self._chk(self._L.rlh_b_solid(self._b, c.ctypes.data))
+
+    def checker(self, scale, even, odd):
+        return self._chk(self._L.rlh_b_checker(self._b, scale, even, odd))
+
+    def image(self, rgb_f32):
+        a = np.ascontiguousarray(rgb_f32, dtype=np.float32)
+        return self._chk(self._L.rlh_b_image(self._b, a.ctypes.data, a.shape[1], a.shape[0]))
+
+    def lambertian(self, tex):
+        return self._chk(self._L.rlh_b_material(self._b, MAT_LAMBERTIAN, tex, None, 0.0, 1.0))
+
+    def metal(self, albedo, fuzz):
+        a = self._v(albedo)
+        return self._chk(self._L.rlh_b_material(self._b, MAT_METAL, -1, a.ctypes.data, fuzz, 1.0))
+
+    def dielectric(self, ior):
+        return self._chk(self._L.rlh_b_material(self._b, MAT_DIELECTRIC, -1, None, 0.0, ior))
+
+    def diffuse_light(self, tex):
+        return self._chk(self._L.rlh_b_material(self._b, MAT_DIFFUSE_LIGHT, tex, None, 0.0, 1.0))
+
+    def flat(self):
+        return self._chk(self._L.rlh_b_material(self._b, MAT_FLAT, -1, None, 0.0, 1.0))
+
+    def sphere(self, center, radius, mat, center2=None):
+        c0, c1 = self._v(center), self._v(center2)
+        return self._chk(self._L.rlh_b_sphere(self._b, c0.ctypes.data, None if c1 is None else c1.ctypes.data, radius, mat))
+
+    def _planar(self, kind, q, u, v, mat):
+        q, u, v = self._v(q), self._v(u), self._v(v)
+        return self._chk(self._L.rlh_b_planar(self._b, kind, q.ctypes.data, u.ctypes.data, v.ctypes.data, mat))
+
+    def plane(self, q, u, v, mat):
+        return self._planar(0, q, u, v, mat)
+
+    def quad(self, q, u, v, mat):
+        return self._planar(1, q, u, v, mat)
+
+    def triangle(self, q, u, v, mat):
+        return self._planar(2, q, u, v, mat)
+
+    def triangle_from_model(self, points, mat, uvs=None, normals=None):
+        p, t, n = self._v(points), self._v(uvs), self._v(normals)
+        return self._chk(self._L.rlh_b_triangle(self._b, p.ctypes.data, None if t is None else t.ctypes.data,
+                                                None if n is None else n.ctypes.data, mat))
+
+    def translate(self, obj, offset):
+        o = self._v(offset)
+        return self._chk(self._L.rlh_b_translate(self._b, obj, o.ctypes.data))
+
+    def rotate_x(self, obj, deg):
+        return self._chk(self._L.rlh_b_transform(self._b, obj, 0, deg))
+
+    def rotate_y(self, obj, deg):
+        return self._chk(self._L.rlh_b_transform(self._b, obj, 1, deg))
+
+    def rotate_z(self, obj, deg):
+        return self._chk(self._L.rlh_b_transform(self._b, obj, 2, deg))
+
+    def scale(self, obj, s):
+        return self._chk(self._L.rlh_b_transform(self._b, obj, 3, s))
+
+    def bvh(self, objs):
+        a = np.ascontiguousarray(objs, dtype=np.int32)
+        return self._chk(self._L.rlh_b_group(self._b, a.ctypes.data, len(a), 1))
+
+    def list(self, objs):
+        a = np.ascontiguousarray(objs, dtype=np.int32)
+        return self._chk(self._L.rlh_b_group(self._b, a.ctypes.data, len(a), 0))
+
+    def obj_mesh(self, obj_text: bytes, mat):
+        return self._chk(self._L.rlh_b_obj(self._b, obj_text, len(obj_text), mat))
+
+
+def set_rtiow_variant(v):
+    """Tests / tools: force a kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave)."""
+    L = render_lib()
+    L.rl_debug_set_rtiow_variant.argtypes = [C.c_int]
+    L.rl_debug_set_rtiow_variant(int(v))
 
 
 @dataclass

@@ -16,7 +16,7 @@ struct RtiowCompiler {
   RtiowProgram &p;
   std::string &err;
   std::vector<uint8_t> bvh_busy, list_busy, tr_busy, tf_busy;
-  uint32_t inst_depth = 0;
+  std::vector<uint32_t> push_stack;
 
   bool fail(const std::string &m) {
     err = m;
@@ -113,20 +113,23 @@ struct RtiowCompiler {
         std::vector<uint8_t> &busy = tr ? tr_busy : tf_busy;
         if (busy[h.index]) return fail("cycle through an instance");
         busy[h.index] = 1;
+        uint32_t push_pc = (uint32_t)p.ops.size();
         DevOp op{};
         op.code = tr ? OP_PUSH_TRANSLATE : OP_PUSH_TRANSFORM;
-        op.a = h.index, op.b = NONE;
-        op.skip = (uint32_t)p.ops.size() + 1;
+        op.a = h.index;
+        op.b = push_stack.empty() ? NONE : push_stack.back();  // parent PUSH: the chain back to the world ray
+        op.skip = push_pc + 1;
         p.ops.push_back(op);
         p.has_instances = true;
-        inst_depth++;
-        if (inst_depth > p.max_instance_depth) p.max_instance_depth = inst_depth;
+        push_stack.push_back(push_pc);
+        if (push_stack.size() > p.max_instance_depth) p.max_instance_depth = (uint32_t)push_stack.size();
+        if (push_stack.size() > 8) return fail("instances nested deeper than 8");
         rl_href child = tr ? d.translates[h.index].child : d.transforms[h.index].child;
         if (!emit(child, depth + 1)) return false;
-        inst_depth--;
+        push_stack.pop_back();
         DevOp po{};
         po.code = tr ? OP_POP_TRANSLATE : OP_POP_TRANSFORM;
-        po.a = h.index, po.b = NONE;
+        po.a = h.index, po.b = push_pc;  // matching PUSH
         po.skip = (uint32_t)p.ops.size() + 1;
         p.ops.push_back(po);
         busy[h.index] = 0;

@@ -13,6 +13,7 @@
 #include "rl_program.h"
 #include "rl_rtc_kernel.h"
 #include "rl_rtiow_kernel.h"
+#include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
 
 using namespace rl;
@@ -100,7 +101,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
   g_ready = true;
   return RL_OK;
@@ -156,11 +157,6 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
   std::string err;
   if (compile_rtiow(*desc, s->rt, err) != RL_OK) {
     set_err(RL_E_INVALID, err);
-    delete s;
-    return nullptr;
-  }
-  if (s->rt.has_planars || s->rt.has_instances) {
-    set_err(RL_E_UNSUPPORTED, "planar primitives / instances have no gfx950 kernel yet in this build");
     delete s;
     return nullptr;
   }
@@ -263,7 +259,9 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
-  if (variant == 0) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
+  bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images;
+  if (general || variant == 2) variant = 2;  // the all-primitives kernel (scene read from HBM/L2)
+  if (variant == 0 && !general) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
@@ -275,7 +273,11 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, true, false>, NT, rb, true); \
     else rc = want_stats ? launch(rtiow_wave_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, false, false>, NT, rb, false);   \
   }
-  if (variant == 1) {
+  if (variant == 2) {
+    constexpr int NT = 256;
+    size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
+    rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+  } else if (variant == 1) {
     constexpr int NT = 1024;
     size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
     bool in_lds = rb + scene_bytes <= g_lds_max;
@@ -298,6 +300,9 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   }
   return RL_OK;
 }
+
+// Not part of the ABI (tests / tools only): force an RTIOW kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave).
+void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 
 // Not part of the ABI (tools only): scheduler occupancy counters of the last STATS launch, 32 x u64.
 int rl_debug_sched(const rl_scene *scene, unsigned long long *out32) {

@@ -1,0 +1,333 @@
+// RTIOW general kernel: every Hittable the reference composes on this path — spheres, planes / quads /
+// triangles (flat/plane.rs, quad.rs, triangle.rs), Translate / Transform instances (translate.rs,
+// transform.rs), BVH nodes and plain slices — with Lambertian / Metal / Dielectric / DiffuseLight / Flat
+// materials and Solid / Checker / Image textures.  The scene program is read from HBM through L1/L2
+// (a 1M-sphere BVH is 64 MB of ops + 64 MB of spheres: Infinity-Cache resident, not LDS-sized), the
+// ChaCha block of each lane lives in LDS.  One lane owns one pixel at a time (persistent lanes).
+//
+// Instances: PUSH ops transform the ray into object space (transform.rs:145-149, translate.rs:15);
+// the matching POP transforms the hit found inside back (p, normal; t and face are NOT recomputed,
+// transform.rs:152-161) and restores the parent-space ray by replaying the enclosing PUSH chain from
+// the world ray — the same arithmetic as the first time, so bit-identical — which keeps traversal
+// stackless.
+#pragma once
+#include "rl_rtiow_kernel.h"
+
+namespace rl {
+
+__device__ __forceinline__ D3 mat3_mul(const double *m, D3 v) {  // matrix.rs:42-60: each row accumulates from 0.0
+  double o[3];
+#pragma unroll
+  for (int n = 0; n < 3; n++) {
+    double sum = 0.0;
+    sum += m[3 * n + 0] * v.x;
+    sum += m[3 * n + 1] * v.y;
+    sum += m[3 * n + 2] * v.z;
+    o[n] = sum;
+  }
+  return D3{o[0], o[1], o[2]};
+}
+
+struct Rec {  // hittable/mod.rs:24-30 HitRecord + the material id
+  D3 p, normal;
+  double t, u, v;
+  uint32_t mat;
+  uint32_t pc;  // op where it was found (instance scope test)
+  bool front, any;
+};
+
+__device__ __forceinline__ void face_normal(D3 d, D3 outward, D3 &normal, bool &front) {  // hittable/mod.rs:32-38
+  front = dot(d, outward) <= 0.0;
+  normal = front ? outward : -outward;
+}
+
+// Sphere::hit with the full record (sphere.rs:32-75); returns the from_normalized flag
+__device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payload, uint32_t mat, uint32_t pc, D3 o, D3 d, double time, Rec &r) {
+  D3 c0 = ld3(s.c0);
+  D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+  D3 oc = o - center;
+  double a = len2(d);
+  double half_b = dot(oc, d);
+  double c = len2(oc) - s.r2;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return false;
+  double sq = sqrt(disc);
+  double r_l = (-half_b - sq) / a;
+  double r_u = (-half_b + sq) / a;
+  double t;
+  if (1e-10 <= r_l && r_l <= r.t) t = r_l;
+  else if (1e-10 <= r_u && r_u <= r.t) t = r_u;
+  else return false;
+  D3 p = o + d * t;
+  D3 outward = (p - center) * s.inv_r;
+  double l2 = len2(outward);
+  r.t = t, r.p = p, r.u = 0.0, r.v = 0.0, r.mat = mat, r.pc = pc, r.any = true;
+  face_normal(d, outward, r.normal, r.front);
+  return !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
+}
+
+// Plane::hit_ab + Plane/Quad/Triangle::hit (plane.rs:51-100, quad.rs:37-42, triangle.rs:60-95); returns flag
+__device__ __forceinline__ bool planar_hit_rec(const DevPlanar &pl, uint32_t pc, D3 o, D3 d, Rec &r) {
+  D3 normal = ld3(pl.normal);
+  double denom = dot(normal, d);
+  if (fabs(denom) < 1e-8) return false;
+  double t = (pl.d - dot(normal, o)) / denom;
+  if (!(1e-10 <= t && t <= r.t)) return false;
+  D3 p = o + d * t;
+  D3 hp = p - ld3(pl.q);
+  D3 w = ld3(pl.w);
+  double alpha = dot(w, cross(hp, ld3(pl.v)));
+  double beta = dot(w, cross(ld3(pl.u), hp));
+  bool flag = false;
+  double uu = alpha, vv = beta;
+  D3 n = normal;
+  if (pl.kind == RL_PLANAR_QUAD) {
+    if (!(0.0 <= alpha && alpha <= 1.0 && 0.0 <= beta && beta <= 1.0)) return false;
+  } else if (pl.kind == RL_PLANAR_TRIANGLE) {
+    if (!(0.0 <= alpha && 0.0 <= beta && alpha + beta <= 1.0)) return false;
+    double frac2 = alpha, frac3 = beta, frac1 = 1.0 - alpha - beta;
+    if (pl.has_normals) {
+      D3 nn = (ld3(pl.normals + 3) * frac2 + ld3(pl.normals + 6) * frac3) + ld3(pl.normals) * frac1;
+      double m = len2(nn);
+      if (approx_eq_eps(m, 0.0, 1e-16)) flag = true;  // NormalizedVec3::try_from(..).unwrap() would panic
+      else n = normalize(nn);
+    }
+    if (pl.has_uvs) {
+      uu = pl.uvs[0] * frac1 + pl.uvs[2] * frac2 + pl.uvs[4] * frac3;
+      vv = pl.uvs[1] * frac1 + pl.uvs[3] * frac2 + pl.uvs[5] * frac3;
+    }
+  }
+  r.t = t, r.p = p, r.u = uu, r.v = vv, r.mat = pl.material, r.pc = pc, r.any = true;
+  face_normal(d, n, r.normal, r.front);
+  return flag;
+}
+
+// transform the world ray through the chain of PUSH ops that ends at `push_pc` (NONE: identity)
+__device__ __forceinline__ void replay_chain(const RtiowParams &P, const DevOp *ops, uint32_t push_pc, D3 wo, D3 wd, D3 &o, D3 &d) {
+  uint32_t stack[8];
+  int n = 0;
+  while (push_pc != NONE && n < 8) {
+    stack[n++] = push_pc;
+    push_pc = ops[push_pc].b;
+  }
+  o = wo, d = wd;
+  for (int i = n - 1; i >= 0; i--) {
+    const DevOp &op = ops[stack[i]];
+    if ((op.code & 0xFFu) == OP_PUSH_TRANSLATE) o = o - ld3(P.translates[op.a].offset);
+    else {
+      const rl_transform &t = P.transforms[op.a];
+      D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
+      o = no, d = nd;
+    }
+  }
+}
+
+template <int NT, bool STATS>
+__global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  unsigned long long *s_rng = (unsigned long long *)smem;  // [8][NT]
+  const DevOp *ops = P.ops;
+  RngCtx<NT> rc{P.key, s_rng, tid};
+  const rl_rtiow_camera &cam = P.cam;
+  const uint32_t W = cam.image_width;
+  const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
+  const D3 p00 = ld3(cam.pixel_00), du = ld3(cam.pixel_du), dv = ld3(cam.pixel_dv);
+  const D3 lookfrom = ld3(cam.lookfrom), ddu = ld3(cam.defocus_disk_u), ddv = ld3(cam.defocus_disk_v);
+  const D3 background = ld3(cam.background);
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  unsigned long long c_rays = 0, c_nodes = 0, c_sph = 0, c_pl = 0, c_inst = 0, c_flag = 0, c_words = 0;
+
+  for (;;) {
+    uint32_t slot = wave_claim(P.work_counter);
+    if (slot >= P.n_slots) break;
+    uint32_t tile = slot >> 6, in = slot & 63u;
+    uint32_t x = (tile % P.tiles_x) * 8u + (in & 7u);
+    uint32_t r = (tile / P.tiles_x) * 8u + (in >> 3);
+    if (x >= W || r >= P.nrows) continue;
+    uint32_t y = P.row_first + r * P.row_step;
+    Rng rng{0ull, 0u, 0xFFFFFFFFu};
+    D3 sum = d3(0.0, 0.0, 0.0);
+    for (uint32_t n = 0; n < cam.samples_per_pixel; n++) {
+      uint64_t sample_index = (uint64_t)n + P.first_sample;
+      rng.stream = sample_index * WH + (uint64_t)x * (uint64_t)W + (uint64_t)y;
+      rng.buf_ctr = 0xFFFFFFFFu;
+      D3 pixel_center = (p00 + du * (double)x) + dv * (double)y;
+      double px = -0.5 + rc.gen_f64(rng);
+      double py = -0.5 + rc.gen_f64(rng);
+      D3 pixel_sample = pixel_center + (du * px + dv * py);
+      D3 wo;
+      if (cam.defocus_angle <= 0.0) wo = lookfrom;
+      else {
+        double a, b;
+        rc.unit_disc(rng, a, b);
+        wo = (lookfrom + ddu * a) + ddv * b;
+      }
+      D3 wd = pixel_sample - wo;
+      double time = rc.gen_f64(rng);
+      D3 thr = d3(1.0, 1.0, 1.0);
+      D3 color = d3(0.0, 0.0, 0.0);
+      for (uint32_t depth = cam.max_depth; depth > 0; depth--) {
+        c_rays++;
+        Rec rec;
+        rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.front = true;
+        rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
+        D3 o = wo, d = wd;
+        uint32_t pc = 0;
+        for (;;) {
+          const DevOp &op = ops[pc];
+          uint32_t code = op.code & 0xFFu;
+          if (code == OP_END) break;
+          if (code == OP_BOX || code == OP_BOX_SPH || code == OP_BOX_PLANAR) {
+            if (STATS) c_nodes++;
+            if (!aabb_hit(op.box, o, d, 1e-10, rec.t)) {
+              pc = op.skip;
+              continue;
+            }
+            if (code == OP_BOX) {
+              pc++;
+              continue;
+            }
+            uint32_t a = op.a, b = op.b;
+            if (code == OP_BOX_SPH) {
+              if (STATS) c_sph++;
+              uint32_t ai = a & ~SPH_MOVING;
+              if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
+              if (b != NONE) {
+                if (STATS) c_sph++;
+                uint32_t bi = b & ~SPH_MOVING;
+                if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec)) c_flag++;
+              }
+            } else {
+              if (STATS) c_pl++;
+              if (planar_hit_rec(P.planars[a], pc, o, d, rec)) c_flag++;
+              if (b != NONE) {
+                if (STATS) c_pl++;
+                if (planar_hit_rec(P.planars[b], pc, o, d, rec)) c_flag++;
+              }
+            }
+            pc = op.skip;
+            continue;
+          }
+          if (code == OP_SPHERE) {
+            if (STATS) c_sph++;
+            uint32_t a = op.a, ai = a & ~SPH_MOVING;
+            if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
+            pc++;
+            continue;
+          }
+          if (code == OP_PLANAR) {
+            if (STATS) c_pl++;
+            if (planar_hit_rec(P.planars[op.a], pc, o, d, rec)) c_flag++;
+            pc++;
+            continue;
+          }
+          if (code == OP_PUSH_TRANSLATE) {  // translate.rs:15
+            if (STATS) c_inst++;
+            o = o - ld3(P.translates[op.a].offset);
+            pc++;
+            continue;
+          }
+          if (code == OP_PUSH_TRANSFORM) {  // transform.rs:145-149
+            if (STATS) c_inst++;
+            const rl_transform &t = P.transforms[op.a];
+            D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
+            o = no, d = nd;
+            pc++;
+            continue;
+          }
+          // POP: op.b = pc of the matching PUSH, whose .b is the parent PUSH
+          uint32_t push_pc = op.b;
+          if (rec.any && rec.pc > push_pc) {  // the current closest hit was found inside this instance
+            if (code == OP_POP_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);  // translate.rs:18
+            else {                                                                              // transform.rs:152-161
+              const rl_transform &t = P.transforms[op.a];
+              rec.p = mat3_mul(t.m, rec.p);
+              D3 wn = mat3_mul(t.inv_t, rec.normal);
+              double m = len2(wn);
+              if (approx_eq_eps(m, 0.0, 1e-16)) c_flag++;  // "Instance normal couldn't be normalized"
+              else rec.normal = normalize(wn);
+            }
+          }
+          replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
+          pc++;
+        }
+        if (!rec.any) {
+          color = color + thr * background;
+          break;
+        }
+        const DevMaterial &m = P.materials[rec.mat];
+        uint32_t kind = m.kind;
+        D3 normal = rec.normal, p = rec.p;
+        D3 nd;
+        if (kind == RL_MAT_LAMBERTIAN) {
+          D3 dir = normal + rc.unit_sphere(rng);
+          bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
+          nd = near_zero ? normal : dir;
+          thr = thr * texture_value(P, m.texture, rec.u, rec.v, p);
+        } else if (kind == RL_MAT_METAL) {
+          D3 reflected = wd - normal * (2.0 * dot(wd, normal));
+          nd = normalize(reflected) + rc.unit_sphere(rng) * m.fuzz;
+          if (!(dot(nd, normal) > 0.0)) break;
+          thr = thr * ld3(m.albedo);
+        } else if (kind == RL_MAT_DIELECTRIC) {
+          double ri = rec.front ? 1.0 / m.ior : m.ior;
+          double m2 = len2(wd);
+          D3 ud;
+          if (approx_eq_eps(m2, 0.0, 1e-16)) {
+            c_flag++;
+            ud = wd;
+          } else
+            ud = normalize(wd);
+          double cos_theta = fmin(dot(-ud, normal), 1.0);
+          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+          bool reflect = ri * sin_theta > 1.0;
+          if (!reflect) {
+            double q = (1.0 - ri) / (1.0 + ri);
+            double r0 = q * q;
+            double xx = 1.0 - cos_theta;
+            double x2 = xx * xx;
+            double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
+            reflect = refl > rc.gen_f64(rng);
+          }
+          if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
+          else {
+            D3 perp = (ud + normal * cos_theta) * ri;
+            D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
+            nd = perp + par;
+          }
+        } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
+          color = color + thr * texture_value(P, m.texture, rec.u, rec.v, p);
+          break;
+        } else {
+          break;
+        }
+        wo = p;
+        wd = nd;
+      }
+      sum = sum + color;
+    }
+    c_words += rng.pos;
+    double *outp = P.out + ((size_t)r * W + x) * 3;
+    outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+  }
+  unsigned long long v;
+  v = wave_sum(c_rays);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[0], v);
+  v = wave_sum(c_flag);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[6], v);
+  if (STATS) {
+    v = wave_sum(c_nodes);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[1], v);
+    v = wave_sum(c_sph);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[2], v);
+    v = wave_sum(c_pl);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[3], v);
+    v = wave_sum(c_inst);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[4], v);
+    v = wave_sum(c_words);
+    if ((tid & 63) == 0) atomicAdd(&P.stats[5], v);
+  }
+}
+
+}  // namespace rl

@@ -114,6 +114,128 @@ rlh_rtiow *rlh_rtiow_from_spheres(const rl_sphere *spheres, uint32_t n, const rl
   }
 }
 
+// ---- generic scene builder: compose any world the reference's API can (ids index the builder's tables)
+struct rlh_builder {
+  std::vector<rtiow::TexturePtr> tex;
+  std::vector<rtiow::MaterialPtr> mat;
+  std::vector<rtiow::HittablePtr> obj;
+};
+rlh_builder *rlh_builder_new() { return new rlh_builder(); }
+void rlh_builder_free(rlh_builder *b) { delete b; }
+#define RLH_TRY(expr)           \
+  try {                         \
+    expr;                       \
+  } catch (std::exception & e) { \
+    g_err = e.what();           \
+    return -1;                  \
+  }
+int rlh_b_solid(rlh_builder *b, const double *c) {
+  b->tex.push_back(rtiow::SolidColor(rtiow::Color(c[0], c[1], c[2])));
+  return (int)b->tex.size() - 1;
+}
+int rlh_b_checker(rlh_builder *b, double scale, int even, int odd) {
+  if (even < 0 || odd < 0 || (size_t)even >= b->tex.size() || (size_t)odd >= b->tex.size()) return -1;
+  b->tex.push_back(rtiow::Checker(scale, b->tex[even], b->tex[odd]));
+  return (int)b->tex.size() - 1;
+}
+// linear f32 RGB image, top row first (what texture.rs:58 Image holds)
+int rlh_b_image(rlh_builder *b, const float *rgb, uint32_t w, uint32_t h) {
+  auto img = std::make_shared<rtiow::ImageData>();
+  img->width = w, img->height = h;
+  img->rgb.assign(rgb, rgb + (size_t)w * h * 3);
+  b->tex.push_back(rtiow::Image(img));
+  return (int)b->tex.size() - 1;
+}
+int rlh_b_material(rlh_builder *b, uint32_t kind, int tex, const double *albedo, double fuzz, double ior) {
+  auto m = std::make_shared<rtiow::Material>();
+  m->kind = kind;
+  if (kind == RL_MAT_LAMBERTIAN || kind == RL_MAT_DIFFUSE_LIGHT) {
+    if (tex < 0 || (size_t)tex >= b->tex.size()) return -1;
+    m->texture = b->tex[tex];
+  }
+  if (albedo) m->albedo = rtiow::Color(albedo[0], albedo[1], albedo[2]);
+  m->fuzz = fuzz, m->ior = ior;
+  b->mat.push_back(m);
+  return (int)b->mat.size() - 1;
+}
+static bool okm(rlh_builder *b, int m) { return m >= 0 && (size_t)m < b->mat.size(); }
+static bool oko(rlh_builder *b, int o) { return o >= 0 && (size_t)o < b->obj.size(); }
+int rlh_b_sphere(rlh_builder *b, const double *c0, const double *c1_or_null, double radius, int mat) {
+  if (!okm(b, mat)) return -1;
+  using namespace rtiow;
+  Center c = c1_or_null ? Center::Moving(Point3(c0[0], c0[1], c0[2]), Point3(c1_or_null[0], c1_or_null[1], c1_or_null[2]))
+                        : Center::Stationary(Point3(c0[0], c0[1], c0[2]));
+  b->obj.push_back(std::make_shared<Sphere>(c, radius, b->mat[mat]));
+  return (int)b->obj.size() - 1;
+}
+// kind: RL_PLANAR_PLANE / QUAD / TRIANGLE built from (q, u, v) like Plane::new / Quad::new / Triangle::new
+int rlh_b_planar(rlh_builder *b, uint32_t kind, const double *q, const double *u, const double *v, int mat) {
+  if (!okm(b, mat)) return -1;
+  using namespace rtiow;
+  Point3 Q(q[0], q[1], q[2]);
+  Vec3 U(u[0], u[1], u[2]), V(v[0], v[1], v[2]);
+  RLH_TRY(
+      if (kind == RL_PLANAR_PLANE) b->obj.push_back(std::make_shared<Plane>(Q, U, V, b->mat[mat]));
+      else if (kind == RL_PLANAR_QUAD) b->obj.push_back(std::make_shared<Quad>(Q, U, V, b->mat[mat]));
+      else b->obj.push_back(Triangle::from_quv(Q, U, V, b->mat[mat])))
+  return (int)b->obj.size() - 1;
+}
+// Triangle::from_model(points, texture_coords?, normals?, material)
+int rlh_b_triangle(rlh_builder *b, const double *p9, const double *uv6_or_null, const double *n9_or_null, int mat) {
+  if (!okm(b, mat)) return -1;
+  using namespace rtiow;
+  Point3 pts[3] = {Point3(p9[0], p9[1], p9[2]), Point3(p9[3], p9[4], p9[5]), Point3(p9[6], p9[7], p9[8])};
+  Vec3 ns[3];
+  if (n9_or_null)
+    for (int i = 0; i < 3; i++) ns[i] = Vec3(n9_or_null[3 * i], n9_or_null[3 * i + 1], n9_or_null[3 * i + 2]);
+  RLH_TRY(b->obj.push_back(std::make_shared<Triangle>(pts, uv6_or_null, n9_or_null ? ns : nullptr, b->mat[mat])))
+  return (int)b->obj.size() - 1;
+}
+int rlh_b_translate(rlh_builder *b, int obj, const double *off) {
+  if (!oko(b, obj)) return -1;
+  b->obj.push_back(std::make_shared<rtiow::Translate>(b->obj[obj], rtiow::Vec3(off[0], off[1], off[2])));
+  return (int)b->obj.size() - 1;
+}
+// op: 0 rotate_x, 1 rotate_y, 2 rotate_z (degrees), 3 uniform scale
+int rlh_b_transform(rlh_builder *b, int obj, int op, double value) {
+  if (!oko(b, obj)) return -1;
+  using rtiow::Transform;
+  auto o = b->obj[obj];
+  b->obj.push_back(op == 0 ? Transform::rotate_x(o, value) : op == 1 ? Transform::rotate_y(o, value) : op == 2 ? Transform::rotate_z(o, value) : Transform::scale(o, value));
+  return (int)b->obj.size() - 1;
+}
+int rlh_b_group(rlh_builder *b, const int *objs, uint32_t n, int as_bvh) {
+  std::vector<rtiow::HittablePtr> hs;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!oko(b, objs[i])) return -1;
+    hs.push_back(b->obj[objs[i]]);
+  }
+  RLH_TRY(
+      if (as_bvh) b->obj.push_back(std::make_shared<rtiow::Bvh>(std::move(hs)));
+      else b->obj.push_back(std::make_shared<rtiow::HittableList>(std::move(hs))))
+  return (int)b->obj.size() - 1;
+}
+// OBJ text -> Bvh<Triangle> with one material (io/wavefront_obj.rs to_object)
+int rlh_b_obj(rlh_builder *b, const char *text, uint64_t len, int mat) {
+  if (!okm(b, mat)) return -1;
+  RLH_TRY(b->obj.push_back(scenes::RtiowObj::parse(std::string(text, len)).to_object(b->mat[mat])))
+  return (int)b->obj.size() - 1;
+}
+rlh_rtiow *rlh_b_finish(rlh_builder *b, int root) {
+  if (!oko(b, root)) {
+    g_err = "bad root";
+    return nullptr;
+  }
+  try {
+    scenes::RtiowScene sc;
+    sc.world = b->obj[root];
+    return finish(std::move(sc));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
 const rl_rtiow_scene_desc *rlh_rtiow_desc(const rlh_rtiow *h) { return &h->desc; }
 void rlh_rtiow_free(rlh_rtiow *h) { delete h; }
 

@@ -1,0 +1,95 @@
+"""GPU tier: the all-primitives RTIOW kernel (planes / quads / triangles, Translate / Transform instances,
+Image textures, scene read from HBM) against the CPU oracle.  Same bars as test_gpu_parity.py:
+control-flow counters EXACT, colours within 1e-4 (north_star) and in practice ~1e-13."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+COUNTERS = ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged")
+
+
+def _parity(rl, oracle, world, p, tight=1e-9):
+    cam = rl.Camera(p)
+    gs, cs = {}, {}
+    gpu = cam.render(world, stats=gs).data
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    for k in COUNTERS:
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    assert np.abs(gpu - cpu).max() / p.samples_per_pixel <= TOL
+    assert np.abs(gpu - cpu).max() <= tight * max(1.0, np.abs(cpu).max())
+    return gs
+
+
+def _spot_texture():
+    from PIL import Image
+    root = os.path.dirname(os.path.abspath(__file__))
+    return np.asarray(Image.open(os.path.join(root, "golden", "spot_texture.png")).convert("RGB"))
+
+
+def test_cow_scene_cfg4_reduced(rl, oracle, golden):
+    # BASELINE cfg 4 scene (examples/cow.rs: 5856 textured triangles under scale->rotate_y->translate, Cornell quads,
+    # light quad) at 16:9, reduced to 160x90, 8 spp, depth 40
+    world = rl.World.cow_scene(golden("spot_triangulated.obj.gz"), _spot_texture())
+    p = world.params
+    p.aspect_ratio, p.image_width, p.samples_per_pixel = 16.0 / 9.0, 160, 8
+    gs = _parity(rl, oracle, world, p)
+    assert gs["planar_tests"] > 0 and gs["instance_enters"] > 0
+
+
+def test_composed_scene_all_primitive_kinds(rl, oracle):
+    def scene(b):
+        red = b.lambertian(b.solid((0.8, 0.2, 0.2)))
+        chk = b.lambertian(b.checker(0.5, b.solid((0.1, 0.1, 0.1)), b.solid((0.9, 0.9, 0.9))))
+        mirror = b.metal((0.8, 0.8, 0.8), 0.05)
+        glass = b.dielectric(1.5)
+        light = b.diffuse_light(b.solid((4.0, 4.0, 4.0)))
+        objs = [b.sphere((0, 0, -1), 0.5, red), b.sphere((1.2, 0, -1.5), 0.5, glass), b.sphere((-1.2, 0.1, -1.2), 0.4, mirror, center2=(-1.2, 0.4, -1.2)),
+                b.quad((-3, -0.5, -4), (6, 0, 0), (0, 0, 5), chk), b.triangle((-1, 0.8, -2), (2, 0, 0), (0, 1.5, 0), light),
+                b.plane((0, 0, -6), (1, 0, 0), (0, 1, 0), mirror)]
+        tri = b.triangle_from_model([[0, 0, 0], [1, 0, 0], [0, 1, 0]], red, uvs=[[0, 0], [1, 0], [0, 1]], normals=[[0, 0, 1], [0.2, 0, 1], [0, 0.2, 1]])
+        inner = b.bvh([b.sphere((0, 0, 0), 0.3, red), tri, b.quad((0, 0, 0.2), (0.5, 0, 0), (0, 0.5, 0), glass)])
+        inst = b.translate(b.rotate_z(b.rotate_x(b.scale(inner, 1.5), 25.0), -40.0), (0.3, 0.9, -1.8))
+        return b.bvh(objs[:5] + [inst]) if False else b.list([b.bvh(objs[:5] + [inst]), objs[5]])
+    world = rl.World.build(scene)
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=120, samples_per_pixel=6, max_depth=12, vfov=60.0, lookfrom=(0.2, 0.6, 2.5),
+                        lookat=(0.0, 0.2, -1.0), defocus_angle=0.5, focus_dist=3.0, background=(0.3, 0.4, 0.6), seed=3)
+    gs = _parity(rl, oracle, world, p)
+    assert gs["planar_tests"] > 0 and gs["instance_enters"] > 0 and gs["sphere_tests"] > 0
+
+
+def test_cornell_quads_and_image_textured_quad(rl, oracle):
+    tex = np.linspace(0, 1, 16 * 8 * 3, dtype=np.float32).reshape(8, 16, 3)
+
+    def scene(b):
+        white = b.lambertian(b.solid((0.73, 0.73, 0.73)))
+        green = b.lambertian(b.solid((0.12, 0.45, 0.15)))
+        img = b.lambertian(b.image(tex))
+        light = b.diffuse_light(b.solid((15, 15, 15)))
+        qs = [b.quad((555, 0, 0), (0, 555, 0), (0, 0, 555), green), b.quad((0, 0, 0), (0, 555, 0), (0, 0, 555), img),
+              b.quad((343, 554, 332), (-130, 0, 0), (0, 0, -105), light), b.quad((0, 0, 0), (555, 0, 0), (0, 0, 555), white),
+              b.quad((555, 555, 555), (-555, 0, 0), (0, 0, -555), white), b.quad((0, 0, 555), (555, 0, 0), (0, 555, 0), white)]
+        return b.bvh(qs)
+    world = rl.World.build(scene)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=64, samples_per_pixel=8, max_depth=20, vfov=40.0, lookfrom=(278, 278, -800),
+                        lookat=(278, 278, 0), background=(0, 0, 0))
+    _parity(rl, oracle, world, p)
+
+
+def test_general_kernel_equals_wave_kernel_on_spheres(rl):
+    world = rl.World.bouncing_spheres(1)
+    p = world.params
+    p.image_width, p.samples_per_pixel, p.max_depth = 120, 4, 50
+    cam = rl.Camera(p)
+    a = cam.render(world).data
+    try:
+        rl.api.set_rtiow_variant(2)
+        b = cam.render(world).data
+        rl.api.set_rtiow_variant(1)
+        c = cam.render(world).data
+    finally:
+        rl.api.set_rtiow_variant(0)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
