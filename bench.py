@@ -59,6 +59,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     rl = importlib.import_module("rendering-learning_amd")
+    sharding = importlib.import_module("rendering-learning_amd.sharding")
     rl.init(local_rank)
 
     # ---- workload: configs[1] of BASELINE.json
@@ -81,11 +82,7 @@ def main():
     def step(stats=None):
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step, stats=stats)
         if G > 1:  # the one exchange step of the path: framebuffer rows -> rank 0 over RCCL/xGMI
-            dist.gather(shard, gathered, dst=0)
-            if rank == 0:
-                for g in range(G):
-                    n = rl.api.rows_for(H, g, G)
-                    frame[g::G] = gathered[g][:n]
+            sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
 
     # ---- counters for this exact workload (deterministic: identical for every launch) — untimed
     st = {}
@@ -105,11 +102,7 @@ def main():
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step)
         evs[k][1].record(stream)
         if G > 1:
-            dist.gather(shard, gathered, dst=0)
-            if rank == 0:
-                for g in range(G):
-                    n = rl.api.rows_for(H, g, G)
-                    frame[g::G] = gathered[g][:n]
+            sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
     torch.cuda.synchronize(dev)
     if world_size > 1:
         dist.barrier()
