@@ -146,7 +146,7 @@ def main():
                        "baseline_config": "configs[1]", "sharding": f"rows interleaved over {world_size} rank(s), RCCL gather to rank 0",
                        "rays_per_step": rays, "aabb_tests_per_ray": nodes / rays, "sphere_tests_per_ray": spheres / rays},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rtiow_spheres_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max,
+                         "traffic": traffic, "kernel": "rtiow_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scene is LDS-resident: real HBM traffic is the framebuffer; practical ceiling is FP64 VALU issue under divergence"},
         }
