@@ -508,11 +508,11 @@ class RtcWorld:
     @staticmethod
     def from_arrays(triangles, materials, objects, lights, groups=(), group_items=(), boundeds=(), transformeds=(),
                     max_reflection_depth=5, void_color=(0.0, 0.0, 0.0), camera=None):
-        arrs = dict(triangles=np.ascontiguousarray(triangles, dtype=RTC_TRIANGLE), groups=np.ascontiguousarray(groups, dtype=RTC_GROUP),
-                    group_items=np.ascontiguousarray(group_items, dtype=HREF), boundeds=np.ascontiguousarray(boundeds, dtype=RTC_BOUNDED),
-                    transformeds=np.ascontiguousarray(transformeds, dtype=RTC_TRANSFORMED),
-                    materials=np.ascontiguousarray(materials, dtype=RTC_MATERIAL), objects=np.ascontiguousarray(objects, dtype=HREF),
-                    lights=np.ascontiguousarray(lights, dtype=RTC_LIGHT))
+        def arr(x, dt):
+            return np.zeros(0, dtype=dt) if len(x) == 0 else np.ascontiguousarray(x, dtype=dt)
+        arrs = dict(triangles=arr(triangles, RTC_TRIANGLE), groups=arr(groups, RTC_GROUP), group_items=arr(group_items, HREF),
+                    boundeds=arr(boundeds, RTC_BOUNDED), transformeds=arr(transformeds, RTC_TRANSFORMED),
+                    materials=arr(materials, RTC_MATERIAL), objects=arr(objects, HREF), lights=arr(lights, RTC_LIGHT))
         d = RtcSceneDesc()
         for k, a in arrs.items():
             setattr(d, k, a.ctypes.data if len(a) else None)
