@@ -254,6 +254,18 @@ class World:
         return World(host_lib().rlh_rtiow_cow_scene(obj_text, len(obj_text), rgb8.ctypes.data, w, h))
 
     @staticmethod
+    def stress_scene(n_side=1000, subdiv=2, obj_text: bytes = None, rgb8: np.ndarray = None, seed=5):
+        """BASELINE configs[4]: n_side^2 small spheres + ground + subdivided spot mesh (see host/scenes.hpp)."""
+        L = host_lib()
+        L.rlh_rtiow_stress_scene.restype = C.c_void_p
+        L.rlh_rtiow_stress_scene.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        if obj_text is None:
+            return World(L.rlh_rtiow_stress_scene(n_side, subdiv, None, 0, None, 0, 0, seed))
+        rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w = rgb8.shape[:2]
+        return World(L.rlh_rtiow_stress_scene(n_side, subdiv, obj_text, len(obj_text), rgb8.ctypes.data, w, h, seed))
+
+    @staticmethod
     def from_spheres(spheres, materials, textures, use_bvh):
         spheres = np.ascontiguousarray(spheres, dtype=SPHERE)
         materials = np.ascontiguousarray(materials, dtype=MATERIAL)

@@ -61,6 +61,17 @@ rlh_rtiow *rlh_rtiow_cow_scene(const char *obj_text, uint64_t obj_len, const uin
   }
 }
 
+// BASELINE configs[4] stress scene (scenes.hpp::stress_scene); obj_text may be NULL (spheres only)
+rlh_rtiow *rlh_rtiow_stress_scene(int n_side, int subdiv, const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h,
+                                  uint64_t seed) {
+  try {
+    return finish(scenes::stress_scene(n_side, subdiv, obj_text ? std::string(obj_text, obj_len) : std::string(), rgb8, w, h, seed));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
 // Generic: a world of spheres, either a plain slice (use_bvh=0, `[Sphere]`) or Bvh::new(spheres).
 // materials/textures are rl_render.h PODs; sphere.material indexes `materials`.
 rlh_rtiow *rlh_rtiow_from_spheres(const rl_sphere *spheres, uint32_t n, const rl_material *materials, uint32_t n_mat,

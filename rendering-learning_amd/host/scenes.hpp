@@ -287,6 +287,96 @@ inline RtiowScene cow_scene(const std::string &obj_text, const uint8_t *rgb8, ui
   return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
 }
 
+// BASELINE configs[4] ("1M random spheres + 100k-triangle OBJ"): NOT in the reference — defined by
+// SURVEY.md §8d item 5 and frozen here.  n_side = 1000, subdiv = 2 gives 1,000,000 small spheres + the
+// ground sphere + spot_triangulated.obj midpoint-subdivided twice (5856 * 16 = 93,696 triangles, UVs
+// interpolated) under cow.rs's transform chain scaled x0.05 and centred on the origin:
+// scale(10) -> rotate_y(45) -> translate(0, 8.25, 0).  Materials are chosen exactly as
+// bouncing_spheres.rs:38-83 (0.8 / 0.95 thresholds, moving diffuse spheres) but without the
+// (4,0.2,0) exclusion; Xoshiro256++ seed 5.  Camera: bouncing_spheres' (caller sets W / spp / depth).
+// Only the CPU oracle pins this config.
+inline RtiowScene stress_scene(int n_side, int subdiv, const std::string &obj_text, const uint8_t *rgb8, uint32_t tw, uint32_t th,
+                               uint64_t seed = 5) {
+  using namespace rtiow;
+  auto rng = Xoshiro256PlusPlus::seed_from_u64(seed);
+  std::vector<HittablePtr> world;
+  auto checker = Checker(0.32, SolidColor(Color(0.2, 0.23, 0.1)), SolidColor(Color(0.9, 0.9, 0.9)));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, -1e6, 0.0)), 1e6, Lambertian(checker)));
+  int half = n_side / 2;
+  for (int a = -half; a < n_side - half; a++)
+    for (int b = -half; b < n_side - half; b++) {
+      double choose_mat = rng.gen_f64();
+      double cx = (double)a + 0.9 * rng.gen_f64();
+      double cz = (double)b + 0.9 * rng.gen_f64();
+      Point3 center_point(cx, 0.2, cz);
+      if (choose_mat < 0.8) {
+        Point3 center2 = center_point + Vec3(0.0, rng.gen_range(0.0, 0.5), 0.0);
+        double r1 = rng.gen_f64(), g1 = rng.gen_f64(), b1 = rng.gen_f64();
+        double r2 = rng.gen_f64(), g2 = rng.gen_f64(), b2 = rng.gen_f64();
+        world.push_back(std::make_shared<Sphere>(Center::Moving(center_point, center2), 0.2, Lambertian(SolidColor(Color(r1, g1, b1) * Color(r2, g2, b2)))));
+      } else if (choose_mat < 0.95) {
+        double r = rng.gen_range(0.5, 1.0), g = rng.gen_range(0.5, 1.0), bb = rng.gen_range(0.5, 1.0);
+        double fuzz = rng.gen_f64();
+        world.push_back(std::make_shared<Sphere>(Center::Stationary(center_point), 0.2, Metal(Color(r, g, bb), fuzz)));
+      } else {
+        world.push_back(std::make_shared<Sphere>(Center::Stationary(center_point), 0.2, Dielectric(1.5)));
+      }
+    }
+  if (!obj_text.empty()) {
+    auto img = std::make_shared<ImageData>();
+    img->width = tw, img->height = th;
+    img->rgb.resize((size_t)tw * th * 3);
+    for (size_t i = 0; i < img->rgb.size(); i++) img->rgb[i] = (float)srgb::srgb_to_linear((double)((float)rgb8[i] / 255.0f));
+    auto surface = Lambertian(Image(img));
+    RtiowObj obj = RtiowObj::parse(obj_text);
+    std::vector<RtiowObj::Tri> tris;
+    for (auto &g : obj.groups)
+      for (auto &t : g.second) tris.push_back(t);
+    for (int s = 0; s < subdiv; s++) {  // midpoint subdivision: (p0,m01,m20) (m01,p1,m12) (m20,m12,p2) (m01,m12,m20)
+      std::vector<RtiowObj::Tri> next;
+      next.reserve(tris.size() * 4);
+      for (auto &t : tris) {
+        auto midp = [](const Point3 &x, const Point3 &y) { return (x + y) * 0.5; };
+        Point3 m01 = midp(t.p[0], t.p[1]), m12 = midp(t.p[1], t.p[2]), m20 = midp(t.p[2], t.p[0]);
+        double u01[2], u12[2], u20[2];
+        for (int k = 0; k < 2; k++) {
+          u01[k] = (t.uv[k] + t.uv[2 + k]) * 0.5;
+          u12[k] = (t.uv[2 + k] + t.uv[4 + k]) * 0.5;
+          u20[k] = (t.uv[4 + k] + t.uv[k]) * 0.5;
+        }
+        auto mk = [&](const Point3 &a, const double *ua, const Point3 &b, const double *ub, const Point3 &c, const double *uc) {
+          RtiowObj::Tri n{};
+          n.p[0] = a, n.p[1] = b, n.p[2] = c;
+          n.has_uv = t.has_uv, n.has_n = false;
+          n.uv[0] = ua[0], n.uv[1] = ua[1], n.uv[2] = ub[0], n.uv[3] = ub[1], n.uv[4] = uc[0], n.uv[5] = uc[1];
+          next.push_back(n);
+        };
+        mk(t.p[0], t.uv, m01, u01, m20, u20);
+        mk(m01, u01, t.p[1], t.uv + 2, m12, u12);
+        mk(m20, u20, m12, u12, t.p[2], t.uv + 4);
+        mk(m01, u01, m12, u12, m20, u20);
+      }
+      tris.swap(next);
+    }
+    std::vector<HittablePtr> ths;
+    for (auto &t : tris) ths.push_back(std::make_shared<Triangle>(t.p, t.has_uv ? t.uv : nullptr, nullptr, surface));
+    auto mesh = std::make_shared<Bvh>(std::move(ths));
+    world.push_back(std::make_shared<Translate>(Transform::rotate_y(Transform::scale(mesh, 10.0), 45.0), Vec3(0.0, 8.25, 0.0)));
+  }
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0;
+  p.image_width = 3840;
+  p.samples_per_pixel = 4096;
+  p.max_depth = 50;
+  p.vfov = 20.0;
+  p.lookfrom = Point3(13.0, 2.0, 3.0);
+  p.lookat = Point3(0.0, 0.0, 0.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.6;
+  p.focus_dist = 10.0;
+  return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
+}
+
 // ------------------------------------------------------------------ RTC
 struct RtcScene {
   rtc::World world;

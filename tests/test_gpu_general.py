@@ -93,3 +93,13 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
     finally:
         rl.api.set_rtiow_variant(0)
     assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_stress_scene_cfg5_reduced(rl, oracle, golden):
+    # BASELINE configs[4] generator (grid of spheres + ground + subdivided spot mesh under an instance chain), reduced:
+    # 60x60 spheres, one subdivision (23,424 triangles), 128x72, 4 spp, depth 50
+    world = rl.World.stress_scene(60, 1, golden("spot_triangulated.obj.gz"), _spot_texture())
+    p = world.params
+    p.image_width, p.samples_per_pixel, p.max_depth = 128, 4, 50
+    gs = _parity(rl, oracle, world, p)
+    assert gs["planar_tests"] > 0 and gs["sphere_tests"] > 0 and gs["instance_enters"] > 0

@@ -1,0 +1,57 @@
+"""Single-GPU measurements of BASELINE configs[2..4] (the non-headline configs) at reduced sample counts,
+each with a row-subsampled parity check against the CPU oracle.  Prints one JSON line per config."""
+import gzip, importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+rl = importlib.import_module("rendering-learning_amd")
+import rl_oracle as oracle
+from PIL import Image
+
+rl.init(0)
+G = os.path.join(ROOT, "tests", "golden")
+which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
+
+
+def rtiow(name, world, p, check_step):
+    cam = rl.Camera(p)
+    st = {}
+    t0 = time.perf_counter()
+    gpu = cam.render(world, stats=st).data
+    wall = time.perf_counter() - t0
+    cs = {}
+    cpu = oracle.rtiow_render(world.desc, cam.c, row_first=0, row_step=check_step, stats=cs)
+    err = float(np.abs(gpu[0::check_step] - cpu).max()) / p.samples_per_pixel
+    alg = 64 * st["node_tests"] + 64 * st["sphere_tests"] + 128 * st["planar_tests"] + 216 * st["instance_enters"] + 208 * st["rays"]
+    print(json.dumps({"config": name, "W": cam.c.image_width, "H": cam.c.image_height, "spp": p.samples_per_pixel, "depth": p.max_depth,
+                      "rays": st["rays"], "kernel_ms": st["kernel_ms"], "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
+                      "per_ray": {k: st[k] / st["rays"] for k in ("node_tests", "sphere_tests", "planar_tests", "instance_enters")},
+                      "alg_GBps": alg / st["kernel_ms"] / 1e6, "max_abs_err_vs_oracle_rows": err, "oracle_rows_step": check_step, "wall_s": wall}), flush=True)
+
+
+if "cfg3" in which:
+    w = rl.RtcWorld.test_obj_scene(open(os.path.join(G, "teapot-low.obj"), "rb").read(), 1920, 1080)
+    for aa in (1, 8):
+        st = {}
+        img = w.render(aa, stats=st)
+        cpu = oracle.rtc_render(w.desc, w.camera, aa=aa, row_first=0, row_step=40)
+        err = float(np.abs(img[0::40] - cpu).max())
+        alg = 48 * st["node_tests"] + 72 * st["planar_tests"]
+        print(json.dumps({"config": "cfg3 RTC teapot 1920x1080", "aa": aa, "rays": st["rays"], "kernel_ms": st["kernel_ms"],
+                          "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3, "tri_tests_per_ray": st["planar_tests"] / st["rays"],
+                          "alg_GBps": alg / st["kernel_ms"] / 1e6, "max_abs_err_vs_oracle_rows": err}), flush=True)
+if "cfg4" in which or "cfg5" in which:
+    tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
+    obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
+if "cfg4" in which:
+    w = rl.World.cow_scene(obj, tex)
+    p = w.params
+    p.aspect_ratio, p.image_width, p.samples_per_pixel = 16.0 / 9.0, 3840, int(os.environ.get("CFG4_SPP", "16"))
+    rtiow("cfg4 cow 3840x2160 (spp reduced from 512)", w, p, 120)
+if "cfg5" in which:
+    t0 = time.perf_counter()
+    w = rl.World.stress_scene(1000, 2, obj, tex)
+    print(json.dumps({"cfg5_scene_build_s": time.perf_counter() - t0}), flush=True)
+    p = w.params
+    p.samples_per_pixel = int(os.environ.get("CFG5_SPP", "4"))
+    rtiow("cfg5 1M spheres + 93,696 tris 3840x2160 (spp reduced from 4096)", w, p, 240)
