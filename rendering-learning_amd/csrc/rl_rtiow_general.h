@@ -11,7 +11,7 @@
 // the world ray — the same arithmetic as the first time, so bit-identical — which keeps traversal
 // stackless.
 #pragma once
-#include "rl_rtiow_kernel.h"
+#include "rl_rtiow_wave.h"  // RayAux / aabb_fast (filtered AABB test with exact fallback)
 
 namespace rl {
 
@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
         rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.front = true;
         rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
         D3 o = wo, d = wd;
+        RayAux ra = ray_aux(o, d);
         uint32_t pc = 0;
         for (;;) {
           const DevOp &op = ops[pc];
@@ -180,7 +181,11 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           if (code == OP_END) break;
           if (code == OP_BOX || code == OP_BOX_SPH || code == OP_BOX_PLANAR) {
             if (STATS) c_nodes++;
-            if (!aabb_hit(op.box, o, d, 1e-10, rec.t)) {
+            double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+            bool certain;
+            bool hitb = aabb_fast(bx, ra, rec.t, certain);
+            if (!(certain && ra.fast_ok && (op.code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, rec.t);  // rare: the reference's divisions
+            if (!hitb) {
               pc = op.skip;
               continue;
             }
@@ -225,6 +230,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           if (code == OP_PUSH_TRANSLATE) {  // translate.rs:15
             if (STATS) c_inst++;
             o = o - ld3(P.translates[op.a].offset);
+            ra = ray_aux(o, d);
             pc++;
             continue;
           }
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
             const rl_transform &t = P.transforms[op.a];
             D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
             o = no, d = nd;
+            ra = ray_aux(o, d);
             pc++;
             continue;
           }
@@ -250,6 +257,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
             }
           }
           replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
+          ra = ray_aux(o, d);
           pc++;
         }
         if (!rec.any) {
