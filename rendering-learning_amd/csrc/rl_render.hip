@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -28,6 +29,7 @@ int g_cus = 0;
 size_t g_lds_max = 65536;
 hipStream_t g_stream = nullptr;  // library-owned stream for the host-buffer entry points
 int g_rtiow_variant = 0;         // 0 = automatic; see RL_RTIOW_KERNEL in rl_rtiow_render_device
+bool g_lpt = true;               // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
 
 int set_err(int code, const std::string &m) {
   g_err = m;
@@ -73,6 +75,9 @@ struct rl_scene {
   // per-scene scratch: [0] work counter (u32), [8..] 8 x u64 stats
   unsigned char *d_scratch = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
+  uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr;
+  size_t lpt_pix = 0, lpt_tiles = 0;
 };
 
 extern "C" {
@@ -103,6 +108,7 @@ int rl_init(int device) {
     std::string sv(v);
     g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
+  if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
   return RL_OK;
 }
@@ -130,6 +136,7 @@ void rl_scene_destroy(rl_scene *s) {
   hipFree(s->d_ops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
+  hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   delete s;
@@ -249,11 +256,13 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     if (per_cu < 1) per_cu = 1;
     if (per_cu * nt > 2048) per_cu = 2048 / nt;
     if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
+    if (const char *b = std::getenv("RL_BLOCKS")) {  // A/B only
+      unsigned nb = (unsigned)std::atoi(b);
+      if (nb >= 1 && nb < blocks) blocks = nb;
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
     HIP_TRY(hipGetLastError());
-    if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
     return RL_OK;
   };
   // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
@@ -265,7 +274,8 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
-  int rc;
+  auto launch_variant = [&]() -> int {
+    int rc;
 #define RL_LAUNCH_WAVE(NT)                                                                                              \
   {                                                                                                                     \
     size_t rb = (size_t)16 * NT * sizeof(unsigned long long);                                                           \
@@ -273,21 +283,68 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, true, false>, NT, rb, true); \
     else rc = want_stats ? launch(rtiow_wave_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, false, false>, NT, rb, false);   \
   }
-  if (variant == 2) {
-    constexpr int NT = 256;
-    size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
-    rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
-  } else if (variant == 1) {
-    constexpr int NT = 1024;
-    size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
-    bool in_lds = rb + scene_bytes <= g_lds_max;
-    if (in_lds) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_spheres_kernel<NT, true, false>, NT, rb, true);
-    else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_spheres_kernel<NT, false, false>, NT, rb, false);
-  } else if (variant == 768) RL_LAUNCH_WAVE(768)
-  else if (variant == 1024) RL_LAUNCH_WAVE(1024)
-  else if (variant == 256) RL_LAUNCH_WAVE(256)
-  else RL_LAUNCH_WAVE(512)
+    if (variant == 2) {
+      constexpr int NT = 256;
+      size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
+      rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+    } else if (variant == 1) {
+      constexpr int NT = 1024;
+      size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
+      bool in_lds = rb + scene_bytes <= g_lds_max;
+      if (in_lds) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_spheres_kernel<NT, true, false>, NT, rb, true);
+      else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_spheres_kernel<NT, false, false>, NT, rb, false);
+    } else if (variant == 768) RL_LAUNCH_WAVE(768)
+    else if (variant == 1024) RL_LAUNCH_WAVE(1024)
+    else if (variant == 256) RL_LAUNCH_WAVE(256)
+    else RL_LAUNCH_WAVE(512)
 #undef RL_LAUNCH_WAVE
+    return rc;
+  };
+  P.sample_begin = 0, P.sample_end = cam->samples_per_pixel, P.resume = 0;
+  P.pos_state = nullptr, P.tile_order = nullptr, P.tile_cost = nullptr;
+  // Cost-sorted two-phase render (wave kernels, spp >= 64): a short first launch renders samples [0, 8) of every
+  // pixel and records each 8x8 tile's ray count; the tiles are then sorted by cost and the remaining samples are
+  // rendered expensive-tiles-first (LPT), so the tail of the launch holds cheap pixels only.  Pixels are resumed
+  // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
+  const bool lpt_enabled = g_lpt;
+  const uint32_t lpt_first = 8;
+  bool lpt = lpt_enabled && variant >= 256 && cam->samples_per_pixel >= 64;
+  if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
+  int rc = RL_OK;
+  if (!lpt) rc = launch_variant();
+  else {
+    rl_scene *ms = const_cast<rl_scene *>(scene);  // scratch buffers only; the scene program itself is immutable
+    size_t npix = (size_t)nrows * W, ntiles = (size_t)(slots >> 6);
+    if (ms->lpt_pix < npix) {
+      hipFree(ms->d_pos);
+      ms->d_pos = nullptr, ms->lpt_pix = 0;
+      HIP_TRY(hipMalloc((void **)&ms->d_pos, npix * sizeof(uint32_t)));
+      ms->lpt_pix = npix;
+    }
+    if (ms->lpt_tiles < ntiles) {
+      hipFree(ms->d_tile_cost), hipFree(ms->d_tile_order);
+      ms->d_tile_cost = ms->d_tile_order = nullptr, ms->lpt_tiles = 0;
+      HIP_TRY(hipMalloc((void **)&ms->d_tile_cost, ntiles * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void **)&ms->d_tile_order, ntiles * sizeof(uint32_t)));
+      ms->lpt_tiles = ntiles;
+    }
+    HIP_TRY(hipMemsetAsync(ms->d_tile_cost, 0, ntiles * sizeof(uint32_t), stream));
+    P.sample_end = lpt_first, P.pos_state = ms->d_pos, P.tile_cost = ms->d_tile_cost;
+    rc = launch_variant();
+    if (rc != RL_OK) return rc;
+    std::vector<uint32_t> cost(ntiles), order(ntiles);
+    HIP_TRY(hipMemcpyAsync(cost.data(), ms->d_tile_cost, ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < ntiles; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    HIP_TRY(hipMemcpyAsync(ms->d_tile_order, order.data(), ntiles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `order` is a local: the copy must have left host memory
+    HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
+    P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
+    P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
+    rc = launch_variant();
+  }
+  if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
   if (rc != RL_OK) return rc;
   if (want_stats) {
     unsigned long long h[8];
@@ -303,6 +360,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
 
 // Not part of the ABI (tests / tools only): force an RTIOW kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave).
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
+void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
 
 // Not part of the ABI (tools only): scheduler occupancy counters of the last STATS launch, 32 x u64.
 int rl_debug_sched(const rl_scene *scene, unsigned long long *out32) {

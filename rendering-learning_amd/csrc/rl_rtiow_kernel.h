@@ -31,6 +31,10 @@ struct RtiowParams {
   uint32_t tiles_x, n_slots;
   uint32_t *work_counter;
   double *out;
+  uint32_t sample_begin, sample_end, resume;  // wave kernel: this launch renders samples [begin, end); resume = continue saved pixels
+  uint32_t *pos_state;                         // per-pixel ChaCha word position (saved at pixel end when non-null)
+  const uint32_t *tile_order;                  // slot>>6 -> tile (LPT order) or null
+  uint32_t *tile_cost;                         // per-tile ray count accumulated at pixel end, or null
   uint32_t tune[4];           // wave kernel: [0] max TRAV steps per scheduling round, [1] leave-TRAV population floor in 1/16ths
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
 };

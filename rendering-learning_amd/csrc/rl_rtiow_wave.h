@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   }
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
-  const uint32_t spp = cam.samples_per_pixel;
+  const uint32_t s_begin = P.sample_begin, spp = P.sample_end;  // this launch renders samples [s_begin, spp) of every pixel
   const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
   const double INF = __longlong_as_double(0x7FF0000000000000ll);
 
@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   Ring<NT> rng{P.key, s_rng, tid, 0ull, 0u, 0u, 0u};
   uint32_t state = ST_GEN;
   uint32_t px = 0, pr = 0, n = spp;  // n == spp: no pixel owned yet
+  uint32_t ptile = 0, pix_rays = 0;
   bool have_pixel = false;
   D3 sum = d3(0.0, 0.0, 0.0);
   D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), thr = d3(1.0, 1.0, 1.0);
@@ -241,9 +242,12 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
         bool active = true;
         if (n >= spp) {  // pixel finished (or none yet): write it out, claim the next slot
           if (have_pixel) {
-            double *outp = P.out + ((size_t)pr * W + px) * 3;
+            size_t pix = (size_t)pr * W + px;
+            double *outp = P.out + pix * 3;
             outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
-            if (STATS) c_words += rng.pos;
+            if (P.pos_state) P.pos_state[pix] = rng.pos;               // resumable: the next launch continues this pixel
+            if (P.tile_cost) atomicAdd(&P.tile_cost[ptile], pix_rays);  // cost estimate for the LPT order of the next launch
+            if (STATS && !P.tile_cost) c_words += rng.pos;
             have_pixel = false;
           }
           uint32_t slot = wave_claim(P.work_counter);
@@ -252,15 +256,26 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             active = false;
           } else {
             uint32_t tile = slot >> 6, in = slot & 63u;
+            if (P.tile_order) tile = P.tile_order[tile];  // expensive tiles first
+            ptile = tile;
             px = (tile % P.tiles_x) * 8u + (in & 7u);
             pr = (tile / P.tiles_x) * 8u + (in >> 3);
             if (px >= W || pr >= P.nrows) active = false;  // slot outside the image: stay in GEN, claim again next time
             else {
               have_pixel = true;
-              n = 0;
-              rng.pos = 0;
-              sum = d3(0.0, 0.0, 0.0);
-              if (spp == 0) active = false;
+              n = s_begin;
+              pix_rays = 0;
+              if (P.resume) {  // continue where the previous launch stopped: same sums, same ChaCha word position
+                size_t pix = (size_t)pr * W + px;
+                const double *inp = P.out + pix * 3;
+                sum = d3(inp[0], inp[1], inp[2]);
+                rng.pos = P.pos_state[pix];
+              } else {
+                rng.pos = 0;
+                sum = d3(0.0, 0.0, 0.0);
+              }
+              rng.nres = 0;
+              if (n >= spp) active = false;
             }
           }
         }
@@ -289,6 +304,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             n++;
           } else {
             c_rays++;
+            pix_rays++;
             ra = ray_aux(o, d);
             pc = 0, closest = INF, hit_prim = NONE;
             state = ST_TRAV;
@@ -366,6 +382,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           state = ST_GEN;
         } else {
           c_rays++;
+          pix_rays++;
           o = p;
           d = nd;
           ra = ray_aux(o, d);

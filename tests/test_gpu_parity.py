@@ -138,3 +138,26 @@ def test_rtc_teapot_antialiased_and_sharded(rl, oracle, golden):
     assert np.abs(img - cpu).max() <= 1e-12
     for g in range(4):
         assert np.array_equal(world.render(3, row_first=g, row_step=4), img[g::4])
+
+
+def test_rtiow_cost_sorted_two_phase_render_is_bit_identical(rl, oracle):
+    # spp >= 64 takes the LPT path (8-sample launch, tiles sorted by cost, resumed launch): same bits as one launch
+    world = rl.World.bouncing_spheres(1)
+    p = world.params
+    p.image_width, p.samples_per_pixel, p.max_depth = 100, 64, 50
+    cam = rl.Camera(p)
+    L = rl.api.render_lib()
+    gs = {}
+    a = cam.render(world, stats=gs).data
+    try:
+        L.rl_debug_set_lpt(0)
+        gs0 = {}
+        b = cam.render(world, stats=gs0).data
+    finally:
+        L.rl_debug_set_lpt(1)
+    assert np.array_equal(a, b)
+    for k in COUNTERS:
+        assert gs[k] == gs0[k], k
+    cs = {}
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    _assert_rtiow_parity(a, cpu, p.samples_per_pixel, gs, cs)
