@@ -16,6 +16,7 @@
 #include "rl_rtiow_kernel.h"
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
+#include "rl_rtiow_wavefront.h"
 
 using namespace rl;
 
@@ -78,6 +79,13 @@ struct rl_scene {
   // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
   uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr;
   size_t lpt_pix = 0, lpt_tiles = 0;
+  // wavefront (v3) buffers: per-pixel state, ray and hit records, queues, control words
+  PixState *wf_pix = nullptr;
+  RayRec *wf_ray = nullptr;
+  HitRec *wf_hit = nullptr;
+  uint32_t *wf_qtrav = nullptr, *wf_qshade = nullptr, *wf_qgen = nullptr, *wf_ctl = nullptr;
+  uint8_t *wf_class = nullptr;
+  size_t wf_npix = 0;
 };
 
 extern "C" {
@@ -106,7 +114,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -137,6 +145,7 @@ void rl_scene_destroy(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
+  hipFree(s->wf_pix), hipFree(s->wf_ray), hipFree(s->wf_hit), hipFree(s->wf_qtrav), hipFree(s->wf_qshade), hipFree(s->wf_qgen), hipFree(s->wf_ctl), hipFree(s->wf_class);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   delete s;
@@ -210,6 +219,84 @@ static void read_stats(const unsigned long long *h, float ms, rl_stats *st) {
   st->rays = h[0], st->node_tests = h[1], st->sphere_tests = h[2], st->planar_tests = h[3];
   st->instance_enters = h[4], st->rng_words = h[5], st->flagged = h[6];
   st->kernel_ms = ms;
+}
+
+// Wavefront (v3) driver: one PASS = begin_pass, TRAV, SHADE, GEN (rl_rtiow_wavefront.h); passes are enqueued in
+// chunks and the finished-pixel counter is polled once per chunk.
+static int render_wavefront(const rl_scene *scene, RtiowParams &P, uint32_t nrows, hipStream_t stream, bool want_stats) {
+  rl_scene *ms = const_cast<rl_scene *>(scene);  // work buffers only; the scene program is immutable
+  const uint32_t Wd = P.cam.image_width;
+  size_t npix = (size_t)nrows * Wd;
+  if (npix >= 0xFFFF0000ull) return set_err(RL_E_INVALID, "image too large");
+  if (ms->wf_npix < npix) {
+    hipFree(ms->wf_pix), hipFree(ms->wf_ray), hipFree(ms->wf_hit), hipFree(ms->wf_qtrav), hipFree(ms->wf_qshade), hipFree(ms->wf_qgen);
+    ms->wf_pix = nullptr, ms->wf_ray = nullptr, ms->wf_hit = nullptr, ms->wf_qtrav = ms->wf_qshade = ms->wf_qgen = nullptr, ms->wf_npix = 0;
+    HIP_TRY(hipMalloc((void **)&ms->wf_pix, npix * sizeof(PixState)));
+    HIP_TRY(hipMalloc((void **)&ms->wf_ray, npix * sizeof(RayRec)));
+    HIP_TRY(hipMalloc((void **)&ms->wf_hit, npix * sizeof(HitRec)));
+    HIP_TRY(hipMalloc((void **)&ms->wf_qtrav, 2 * npix * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ms->wf_qgen, npix * sizeof(uint32_t)));
+    ms->wf_npix = npix;
+  }
+  if (!ms->wf_ctl) HIP_TRY(hipMalloc((void **)&ms->wf_ctl, WC_WORDS * sizeof(uint32_t)));
+  WfParams Wp{};
+  Wp.R = P;
+  Wp.pix = ms->wf_pix, Wp.ray = ms->wf_ray, Wp.hit = ms->wf_hit;
+  Wp.q_trav = ms->wf_qtrav, Wp.q_gen = ms->wf_qgen, Wp.ctl = ms->wf_ctl;
+  Wp.npix = (uint32_t)npix;
+
+  constexpr int NTS = 256;  // GEN / SHADE workgroups
+  size_t lds_s = (size_t)8 * NTS * sizeof(unsigned long long);
+  uint32_t flat_blocks = (uint32_t)((npix + NTS - 1) / NTS);
+  uint32_t stage_blocks = flat_blocks < (uint32_t)g_cus * 8 ? flat_blocks : (uint32_t)g_cus * 8;
+  constexpr int NTT = 768;  // TRAV workgroups (12 waves; two per CU = 6 waves/SIMD at <= 80 VGPRs), scene staged in LDS when it fits
+  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
+  bool in_lds = scene_bytes <= g_lds_max;
+  size_t lds_t = in_lds ? scene_bytes : 0;
+  uint32_t per_cu = in_lds ? (uint32_t)(g_lds_max / (scene_bytes ? scene_bytes : 1)) : 2;
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  uint32_t trav_blocks = (uint32_t)g_cus * per_cu;
+  {
+    uint32_t need = (uint32_t)((npix + NTT - 1) / NTT);
+    if (trav_blocks > need) trav_blocks = need;
+  }
+  if (in_lds) {
+    HIP_TRY(hipFuncSetAttribute((const void *)wf_trav<NTT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    HIP_TRY(hipFuncSetAttribute((const void *)wf_trav<NTT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+  }
+  auto trav = [&]() -> int {
+    if (in_lds) {
+      if (want_stats) hipLaunchKernelGGL((wf_trav<NTT, true, true>), dim3(trav_blocks), dim3(NTT), lds_t, stream, Wp);
+      else hipLaunchKernelGGL((wf_trav<NTT, true, false>), dim3(trav_blocks), dim3(NTT), lds_t, stream, Wp);
+    } else {
+      if (want_stats) hipLaunchKernelGGL((wf_trav<NTT, false, true>), dim3(trav_blocks), dim3(NTT), 0, stream, Wp);
+      else hipLaunchKernelGGL((wf_trav<NTT, false, false>), dim3(trav_blocks), dim3(NTT), 0, stream, Wp);
+    }
+    return RL_OK;
+  };
+  hipLaunchKernelGGL(wf_init, dim3(flat_blocks), dim3(NTS), 0, stream, Wp);
+  hipLaunchKernelGGL((wf_gen<NTS>), dim3(stage_blocks), dim3(NTS), lds_s, stream, Wp);
+  HIP_TRY(hipGetLastError());
+  const int CHUNK = 64;
+  uint32_t finished = 0;
+  for (long pass = 0; pass < (1l << 40); pass += CHUNK) {
+    for (int k = 0; k < CHUNK; k++) {
+      hipLaunchKernelGGL(wf_begin_pass, dim3(1), dim3(1), 0, stream, Wp);
+      int rc = trav();
+      if (rc != RL_OK) return rc;
+      hipLaunchKernelGGL((wf_shade<NTS>), dim3(stage_blocks), dim3(NTS), lds_s, stream, Wp);
+      hipLaunchKernelGGL((wf_gen<NTS>), dim3(stage_blocks), dim3(NTS), lds_s, stream, Wp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&finished, ms->wf_ctl + WC_FINISHED, sizeof finished, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (std::getenv("RL_WF_DEBUG")) std::fprintf(stderr, "[wf] passes %ld finished %u / %zu\n", pass + CHUNK, finished, npix);
+    if (finished >= npix) break;
+  }
+  hipLaunchKernelGGL(wf_finish, dim3(flat_blocks), dim3(NTS), 0, stream, Wp);
+  HIP_TRY(hipGetLastError());
+  return RL_OK;
 }
 
 int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step,
@@ -309,9 +396,11 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
   bool lpt = lpt_enabled && variant >= 256 && cam->samples_per_pixel >= 64;
+  if (variant == 3) P.sample_begin = 0, P.sample_end = cam->samples_per_pixel;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;
-  if (!lpt) rc = launch_variant();
+  if (variant == 3) rc = render_wavefront(scene, P, nrows, stream, want_stats);
+  else if (!lpt) rc = launch_variant();
   else {
     rl_scene *ms = const_cast<rl_scene *>(scene);  // scratch buffers only; the scene program itself is immutable
     size_t npix = (size_t)nrows * W, ntiles = (size_t)(slots >> 6);

@@ -90,9 +90,11 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
         b = cam.render(world).data
         rl.api.set_rtiow_variant(1)
         c = cam.render(world).data
+        rl.api.set_rtiow_variant(3)  # experimental wavefront form: rays in HBM, TRAV / SHADE / GEN kernels per pass
+        d = cam.render(world).data
     finally:
         rl.api.set_rtiow_variant(0)
-    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
 
 
 def test_stress_scene_cfg5_reduced(rl, oracle, golden):
