@@ -16,6 +16,7 @@
 #include "rl_rtiow_kernel.h"
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
+#include "rl_rtiow_wave_general.h"
 #include "rl_rtiow_wavefront.h"
 
 using namespace rl;
@@ -114,7 +115,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -356,7 +357,8 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
   bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images;
-  if (general || variant == 2) variant = 2;  // the all-primitives kernel (scene read from HBM/L2)
+  if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
+  else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
   if (variant == 0 && !general) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
@@ -374,6 +376,10 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       constexpr int NT = 256;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+    } else if (variant == 4) {
+      constexpr int NT = 768;
+      size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
+      rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
     } else if (variant == 1) {
       constexpr int NT = 1024;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
@@ -395,7 +401,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
-  bool lpt = lpt_enabled && variant >= 256 && cam->samples_per_pixel >= 64;
+  bool lpt = lpt_enabled && (variant >= 256 || variant == 4) && cam->samples_per_pixel >= 64;
   if (variant == 3) P.sample_begin = 0, P.sample_end = cam->samples_per_pixel;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;
