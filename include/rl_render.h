@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 1
+#define RL_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ errors */
 #define RL_OK 0
@@ -217,7 +217,13 @@ enum {
   RL_O_TRIANGLE = 1,    /* object/triangle.rs:22 */
   RL_O_GROUP = 2,       /* object/group.rs:14 */
   RL_O_BOUNDED = 3,     /* object/bounded.rs:86 */
-  RL_O_TRANSFORMED = 4  /* object/transformed.rs:12 */
+  RL_O_TRANSFORMED = 4, /* object/transformed.rs:12 */
+  RL_O_SPHERE = 5,      /* object/sphere.rs:10   (index into shapes[]) */
+  RL_O_PLANE = 6,       /* object/plane.rs:11 */
+  RL_O_CUBE = 7,        /* object/cube.rs:10 */
+  RL_O_CYLINDER = 8,    /* object/cylinder.rs:13 */
+  RL_O_CONE = 9,        /* object/cone.rs:13 */
+  RL_O_CSG = 10         /* object/csg.rs:32      (index into csgs[]) */
 };
 
 typedef struct rl_rtc_triangle { /* triangle.rs:22-27 */
@@ -243,11 +249,37 @@ typedef struct rl_rtc_transformed { /* transformed.rs:12-16; row-major 4x4 */
   rl_oref child;
 } rl_rtc_transformed;
 
-typedef struct rl_rtc_material { /* scene/material.rs:22-31; surface = Surface::Color only */
-  double color[3];
+typedef struct rl_rtc_material { /* scene/material.rs:22-31 */
+  double color[3];   /* Surface::Color(c) when pattern == 0 */
   double ambient, diffuse, specular, shininess;
   double reflectivity, transparency, refractive_index;
+  uint32_t pattern;  /* 0: Surface::Color; k > 0: Surface::Pattern(patterns[k-1]) */
+  uint32_t reserved;
 } rl_rtc_material;
+
+/* analytic shapes in their own object space: unit sphere, xz plane, [-1,1]^3 cube, y-axis cylinder / double cone */
+typedef struct rl_rtc_shape { /* object/{sphere,plane,cube,cylinder,cone}.rs */
+  uint32_t kind;      /* RL_O_SPHERE .. RL_O_CONE */
+  uint32_t material;
+  uint32_t has_minimum, has_maximum; /* cylinder / cone: Option<f64> */
+  uint32_t closed, reserved;
+  double minimum, maximum;
+} rl_rtc_shape;
+
+enum { RL_CSG_UNION = 0, RL_CSG_INTERSECTION = 1, RL_CSG_DIFFERENCE = 2 };
+typedef struct rl_rtc_csg { /* object/csg.rs:9-36 */
+  uint32_t operation;
+  uint32_t reserved;
+  rl_oref left, right;
+} rl_rtc_csg;
+
+enum { RL_PAT_STRIPE = 1, RL_PAT_RING = 2, RL_PAT_GRADIENT = 3, RL_PAT_CHECKER3D = 4 };
+typedef struct rl_rtc_pattern { /* scene/pattern/{stripe,ring,gradient,checker3d}.rs: two colours + the pattern's own transform.inverse() (row-major) */
+  uint32_t kind;
+  uint32_t reserved;
+  double a[3], b[3];
+  double inverse[16];
+} rl_rtc_pattern;
 
 typedef struct rl_rtc_light { /* scene/light.rs:4-7 */
   double position[3];
@@ -266,6 +298,9 @@ typedef struct rl_rtc_scene_desc { /* scene/world.rs:26-31 */
   uint32_t max_reflection_depth;
   uint32_t reserved;
   double void_color[3];
+  const rl_rtc_shape *shapes;             uint32_t n_shapes;
+  const rl_rtc_csg *csgs;                 uint32_t n_csgs;
+  const rl_rtc_pattern *patterns;         uint32_t n_patterns;
 } rl_rtc_scene_desc;
 
 typedef struct rl_rtc_camera { /* scene/camera.rs:11-19: the derived fields + transform.inverse() */

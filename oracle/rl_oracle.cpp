@@ -529,6 +529,188 @@ inline void sort_xs(std::vector<Isect> &xs) {  // intersect.rs:170-172 (stable)
 
 void intersect_oref(RtcCtx &cx, rl_oref o, const RRay &ray, std::vector<Isect> &out);
 
+// leaf identity: triangles first, then shapes (object identity in intersect.rs:72-99, world.rs:117)
+inline uint32_t leaf_material(const rl_rtc_scene_desc &d, uint32_t leaf) {
+  return leaf < d.n_triangles ? d.triangles[leaf].material : d.shapes[leaf - d.n_triangles].material;
+}
+inline int64_t f2i64(double f) {  // Rust `as i64`: saturating, NaN -> 0
+  if (std::isnan(f)) return 0;
+  if (f >= 9223372036854775807.0) return INT64_MAX;
+  if (f <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)f;
+}
+// Surface::color_at (material.rs:13-20) -> Pattern::at (pattern/mod.rs:9-11) -> at_local
+V3 surface_color_at(const rl_rtc_scene_desc &d, const rl_rtc_material &m, P3 p);
+
+// build_basic_intersection (object/mod.rs:20-32): colour and normal are evaluated at the LOCAL-space point
+void emit_shape_hit(RtcCtx &cx, const rl_rtc_shape &sh, uint32_t leaf, const RRay &ray, double t, V3 normal, std::vector<Isect> &out) {
+  P3 p = padd(ray.o, ray.d * t);
+  out.push_back(Isect{t, leaf, surface_color_at(*cx.d, cx.d->materials[sh.material], p), normal});
+}
+inline V3 nrm_or_flag(RtcCtx &cx, V3 v) {  // NormalizedVec3d::new(..).unwrap()
+  V3 n;
+  if (!norm(v, n)) {
+    cx.c.flagged++;
+    return V3{0, 0, 0};
+  }
+  return n;
+}
+inline bool in_bounds(const rl_rtc_shape &s, double y) {  // cylinder.rs:21-28 / cone.rs:21-28 (strict)
+  if (s.has_minimum && s.has_maximum) return y > s.minimum && y < s.maximum;
+  if (s.has_minimum) return y > s.minimum;
+  if (s.has_maximum) return y < s.maximum;
+  return true;
+}
+
+void intersect_shape(RtcCtx &cx, uint32_t index, const RRay &ray, std::vector<Isect> &out) {
+  const rl_rtc_scene_desc &d = *cx.d;
+  const rl_rtc_shape &sh = d.shapes[index];
+  uint32_t leaf = d.n_triangles + index;
+  const double EPS = 1e-8;
+  double ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+  auto point_at = [&](double t) { return padd(ray.o, ray.d * t); };
+  switch (sh.kind) {
+    case RL_O_SPHERE: {  // sphere.rs:36-60
+      cx.c.sphere_tests++;
+      V3 s2r = sub(ray.o, P3{0.0, 0.0, 0.0});
+      double a = dot(ray.d, ray.d);
+      double b = 2.0 * dot(ray.d, s2r);
+      double c = dot(s2r, s2r) - 1.0;
+      double disc = b * b - 4.0 * a * c;
+      if (disc < 0.0) return;
+      double sq = std::sqrt(disc);
+      double ts[2] = {(-b - sq) / (2.0 * a), (-b + sq) / (2.0 * a)};
+      for (double t : ts) {
+        P3 p = point_at(t);
+        emit_shape_hit(cx, sh, leaf, ray, t, nrm_or_flag(cx, sub(p, P3{0.0, 0.0, 0.0})), out);
+      }
+      return;
+    }
+    case RL_O_PLANE: {  // plane.rs:27-42
+      cx.c.planar_tests++;
+      if (std::fabs(dy) < 1e-8) return;
+      double t = -oy / dy;
+      emit_shape_hit(cx, sh, leaf, ray, t, V3{0.0, 1.0, 0.0}, out);
+      return;
+    }
+    case RL_O_CUBE: {  // cube.rs:37-78
+      cx.c.planar_tests++;
+      auto axis = [](double origin, double direction, double &lo, double &hi) {
+        double tmin = (-1.0 - origin) / direction;
+        double tmax = (1.0 - origin) / direction;
+        if (tmin > tmax) lo = tmax, hi = tmin;
+        else lo = tmin, hi = tmax;
+      };
+      double xl, xh, yl, yh, zl, zh;
+      axis(ox, dx, xl, xh), axis(oy, dy, yl, yh), axis(oz, dz, zl, zh);
+      double tmin = std::fmax(std::fmax(xl, yl), zl);
+      double tmax = std::fmin(std::fmin(xh, yh), zh);
+      if (tmin > tmax) return;
+      double ts[2] = {tmin, tmax};
+      for (double t : ts) {  // normal_at cube.rs:15-30
+        P3 p = point_at(t);
+        double ax = std::fabs(p.x), ay = std::fabs(p.y), az = std::fabs(p.z);
+        double mc = std::fmax(std::fmax(ax, ay), az);
+        V3 n = (mc == ax) ? V3{p.x, 0.0, 0.0} : (mc == ay) ? V3{0.0, p.y, 0.0} : V3{0.0, 0.0, p.z};
+        emit_shape_hit(cx, sh, leaf, ray, t, nrm_or_flag(cx, n), out);
+      }
+      return;
+    }
+    case RL_O_CYLINDER: {  // cylinder.rs:30-140
+      cx.c.planar_tests++;
+      std::vector<double> ts;
+      double a = dx * dx + dz * dz;
+      if (!(std::fabs(a) < EPS)) {
+        double b = 2.0 * ox * dx + 2.0 * oz * dz;
+        double c = ox * ox + oz * oz - 1.0;
+        double disc = b * b - 4.0 * a * c;
+        if (!(disc < 0.0)) {
+          double t0 = (-b - std::sqrt(disc)) / (2.0 * a);
+          double t1 = (-b + std::sqrt(disc)) / (2.0 * a);
+          double y0 = oy + t0 * dy;
+          if (in_bounds(sh, y0)) ts.push_back(t0);
+          double y1 = oy + t1 * dy;
+          if (in_bounds(sh, y1)) ts.push_back(t1);
+        }
+      }
+      if (sh.closed && !(std::fabs(dy) < EPS)) {
+        auto check_cap = [&](double t) {
+          double x = ox + t * dx, z = oz + t * dz;
+          return x * x + z * z <= 1.0;
+        };
+        if (sh.has_minimum) {
+          double t = (sh.minimum - oy) / dy;
+          if (check_cap(t)) ts.push_back(t);
+        }
+        if (sh.has_maximum) {
+          double t = (sh.maximum - oy) / dy;
+          if (check_cap(t)) ts.push_back(t);
+        }
+      }
+      for (double t : ts) {  // normal_at cylinder.rs:66-84
+        P3 p = point_at(t);
+        double dist2 = p.x * p.x + p.z * p.z;
+        V3 n;
+        if (dist2 < 1.0 && sh.has_maximum && p.y >= sh.maximum - EPS) n = V3{0.0, 1.0, 0.0};
+        else if (dist2 < 1.0 && sh.has_minimum && p.y <= sh.minimum + EPS) n = V3{0.0, -1.0, 0.0};
+        else n = V3{p.x, 0.0, p.z};
+        emit_shape_hit(cx, sh, leaf, ray, t, nrm_or_flag(cx, n), out);
+      }
+      return;
+    }
+    case RL_O_CONE: {  // cone.rs:30-150
+      cx.c.planar_tests++;
+      std::vector<double> ts;
+      double a = dx * dx - dy * dy + dz * dz;
+      double b = 2.0 * ox * dx - 2.0 * oy * dy + 2.0 * oz * dz;
+      double c = ox * ox - oy * oy + oz * oz;
+      bool a0 = std::fabs(a) < EPS, b0 = std::fabs(b) < EPS;
+      if (a0 && b0) {
+      } else if (a0 && !b0) {
+        ts.push_back(-c / (2.0 * b));
+      } else {
+        double disc = b * b - 4.0 * a * c;
+        if (!(disc < 0.0)) {
+          double t0 = (-b - std::sqrt(disc)) / (2.0 * a);
+          double t1 = (-b + std::sqrt(disc)) / (2.0 * a);
+          double y0 = oy + t0 * dy;
+          if (in_bounds(sh, y0)) ts.push_back(t0);
+          double y1 = oy + t1 * dy;
+          if (in_bounds(sh, y1)) ts.push_back(t1);
+        }
+      }
+      if (sh.closed && !(std::fabs(dy) < EPS)) {
+        auto check_cap = [&](double y, double t) {
+          double x = ox + t * dx, z = oz + t * dz;
+          return x * x + z * z <= std::fabs(y);
+        };
+        if (sh.has_minimum) {
+          double t = (sh.minimum - oy) / dy;
+          if (check_cap(sh.minimum, t)) ts.push_back(t);
+        }
+        if (sh.has_maximum) {
+          double t = (sh.maximum - oy) / dy;
+          if (check_cap(sh.maximum, t)) ts.push_back(t);
+        }
+      }
+      for (double t : ts) {  // normal_at cone.rs:62-80
+        P3 p = point_at(t);
+        double dist2 = p.x * p.x + p.z * p.z;
+        V3 n;
+        if (sh.has_maximum && dist2 < sh.maximum * sh.maximum && p.y >= sh.maximum - EPS) n = V3{0.0, 1.0, 0.0};
+        else if (sh.has_minimum && dist2 < sh.minimum * sh.minimum && p.y <= sh.minimum + EPS) n = V3{0.0, -1.0, 0.0};
+        else {
+          double y = std::sqrt(p.x * p.x + p.z * p.z);
+          if (p.y > 0.0) y = -y;
+          n = V3{p.x, y, p.z};
+        }
+        emit_shape_hit(cx, sh, leaf, ray, t, nrm_or_flag(cx, n), out);
+      }
+      return;
+    }
+  }
+}
+
 inline void check_axis(double mn, double mx, double origin, double speed, double &lo, double &hi) {  // bounded.rs:127-139
   double tmin = (mn - origin) / speed;
   double tmax = (mx - origin) / speed;
@@ -563,7 +745,39 @@ void intersect_oref(RtcCtx &cx, rl_oref o, const RRay &ray, std::vector<Isect> &
         }
       } else
         normal = v3(t.n1);
-      out.push_back(Isect{tt, o.index, v3(d.materials[t.material].color), normal});
+      out.push_back(Isect{tt, o.index, surface_color_at(d, d.materials[t.material], padd(ray.o, ray.d * tt)), normal});
+      return;
+    }
+    case RL_O_SPHERE:
+    case RL_O_PLANE:
+    case RL_O_CUBE:
+    case RL_O_CYLINDER:
+    case RL_O_CONE:
+      intersect_shape(cx, o.index, ray, out);
+      return;
+    case RL_O_CSG: {  // csg.rs:78-108
+      const rl_rtc_csg &c = d.csgs[o.index];
+      std::vector<Isect> lx, rx;
+      intersect_oref(cx, c.left, ray, lx);
+      intersect_oref(cx, c.right, ray, rx);
+      struct Sided {
+        Isect i;
+        bool left;
+      };
+      std::vector<Sided> all;
+      for (auto &i : lx) all.push_back(Sided{i, true});
+      for (auto &i : rx) all.push_back(Sided{i, false});
+      std::stable_sort(all.begin(), all.end(), [](const Sided &a, const Sided &b) { return a.i.t < b.i.t; });
+      bool in_l = false, in_r = false;
+      for (auto &x : all) {  // filter_intersections csg.rs:50-74, intersection_allowed :16-28
+        bool allowed;
+        if (c.operation == RL_CSG_UNION) allowed = (x.left && !in_r) || (!x.left && !in_l);
+        else if (c.operation == RL_CSG_INTERSECTION) allowed = (x.left && in_r) || (!x.left && in_l);
+        else allowed = (x.left && !in_r) || (!x.left && in_l);
+        if (x.left) in_l = !in_l;
+        else in_r = !in_r;
+        if (allowed) out.push_back(x.i);
+      }
       return;
     }
     case RL_O_GROUP: {  // group.rs:29-42
@@ -603,6 +817,28 @@ void intersect_oref(RtcCtx &cx, rl_oref o, const RRay &ray, std::vector<Isect> &
       out.insert(out.end(), xs.begin(), xs.end());
       return;
     }
+  }
+}
+
+V3 surface_color_at(const rl_rtc_scene_desc &d, const rl_rtc_material &m, P3 p) {
+  if (m.pattern == 0) return v3(m.color);
+  const rl_rtc_pattern &pt = d.patterns[m.pattern - 1];
+  P3 q = mul_point(pt.inverse, p);  // pattern/mod.rs:9-11
+  V3 a = v3(pt.a), b = v3(pt.b);
+  switch (pt.kind) {
+    case RL_PAT_STRIPE:  // stripe.rs:20-26
+      return (f2i64(std::floor(q.x)) % 2 == 0) ? a : b;
+    case RL_PAT_RING: {  // ring.rs:19-27
+      double radius = std::sqrt(q.x * q.x + q.z * q.z);
+      return (f2i64(std::floor(radius)) % 2 == 0) ? a : b;
+    }
+    case RL_PAT_GRADIENT: {  // gradient.rs:19-24
+      V3 distance = b - a;
+      double fraction = q.x - std::floor(q.x);
+      return a + distance * fraction;
+    }
+    default:  // checker3d.rs:19-25
+      return (f2i64(std::floor(q.x) + std::floor(q.y) + std::floor(q.z)) % 2 == 0) ? a : b;
   }
 }
 
@@ -667,7 +903,7 @@ Comps prepare_computations(RtcCtx &cx, const Isect &isect, const RRay &ray, cons
   }
   std::vector<uint32_t> containers;
   c.n1 = 1.0, c.n2 = 1.0;
-  auto ri = [&](uint32_t tri) { return cx.d->materials[cx.d->triangles[tri].material].refractive_index; };
+  auto ri = [&](uint32_t leaf) { return cx.d->materials[leaf_material(*cx.d, leaf)].refractive_index; };
   for (const auto &i : xs) {
     bool same = are_equal(i.t, isect.t) && i.object == isect.object;
     if (same) c.n1 = containers.empty() ? 1.0 : ri(containers.back());
@@ -699,7 +935,7 @@ double shadow_attenuation(RtcCtx &cx, P3 point, const rl_rtc_light &light) {  //
     if (!(i.t > 0.0 && i.t < distance)) continue;
     if (std::find(seen.begin(), seen.end(), i.object) != seen.end()) break;  // take_while(seen.insert)
     seen.push_back(i.object);
-    prod = prod * cx.d->materials[cx.d->triangles[i.object].material].transparency;
+    prod = prod * cx.d->materials[leaf_material(*cx.d, i.object)].transparency;
   }
   return prod;
 }
@@ -740,7 +976,7 @@ double schlick(const Comps &c) {  // intersect.rs:139-156
 }
 
 bool shade_hit(RtcCtx &cx, const Comps &c, uint32_t remaining, V3 &out) {  // world.rs:57-87
-  const rl_rtc_material &m = cx.d->materials[cx.d->triangles[c.object].material];
+  const rl_rtc_material &m = cx.d->materials[leaf_material(*cx.d, c.object)];
   bool have = false;
   V3 acc{0, 0, 0};
   for (uint32_t li = 0; li < cx.d->n_lights; li++) {

@@ -75,12 +75,18 @@ RTC_GROUP = np.dtype([("first", "<u4"), ("count", "<u4")])
 RTC_BOUNDED = np.dtype([("minimum", "<f8", 3), ("maximum", "<f8", 3), ("child", HREF)])
 RTC_TRANSFORMED = np.dtype([("inverse", "<f8", 16), ("inverse_transpose", "<f8", 16), ("child", HREF)])
 RTC_MATERIAL = np.dtype([("color", "<f8", 3), ("ambient", "<f8"), ("diffuse", "<f8"), ("specular", "<f8"), ("shininess", "<f8"),
-                         ("reflectivity", "<f8"), ("transparency", "<f8"), ("refractive_index", "<f8")])
+                         ("reflectivity", "<f8"), ("transparency", "<f8"), ("refractive_index", "<f8"), ("pattern", "<u4"), ("reserved", "<u4")])
+RTC_SHAPE = np.dtype([("kind", "<u4"), ("material", "<u4"), ("has_minimum", "<u4"), ("has_maximum", "<u4"), ("closed", "<u4"), ("reserved", "<u4"),
+                      ("minimum", "<f8"), ("maximum", "<f8")])
+RTC_CSG = np.dtype([("operation", "<u4"), ("reserved", "<u4"), ("left", HREF), ("right", HREF)])
+RTC_PATTERN = np.dtype([("kind", "<u4"), ("reserved", "<u4"), ("a", "<f8", 3), ("b", "<f8", 3), ("inverse", "<f8", 16)])
 RTC_LIGHT = np.dtype([("position", "<f8", 3), ("intensity", "<f8", 3)])
 
 MAT_FLAT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3, 4
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
-O_TRIANGLE, O_GROUP, O_BOUNDED, O_TRANSFORMED = 1, 2, 3, 4
+O_TRIANGLE, O_GROUP, O_BOUNDED, O_TRANSFORMED, O_SPHERE, O_PLANE, O_CUBE, O_CYLINDER, O_CONE, O_CSG = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = 0, 1, 2
+PAT_STRIPE, PAT_RING, PAT_GRADIENT, PAT_CHECKER3D = 1, 2, 3, 4
 
 
 class RtcSceneDesc(C.Structure):
@@ -93,7 +99,10 @@ class RtcSceneDesc(C.Structure):
                 ("objects", C.c_void_p), ("n_objects", C.c_uint32),
                 ("lights", C.c_void_p), ("n_lights", C.c_uint32),
                 ("max_reflection_depth", C.c_uint32), ("reserved", C.c_uint32),
-                ("void_color", C.c_double * 3)]
+                ("void_color", C.c_double * 3),
+                ("shapes", C.c_void_p), ("n_shapes", C.c_uint32),
+                ("csgs", C.c_void_p), ("n_csgs", C.c_uint32),
+                ("patterns", C.c_void_p), ("n_patterns", C.c_uint32)]
 
 
 # ----------------------------------------------------------------------------- library loading
@@ -518,13 +527,28 @@ class RtcWorld:
         return RtcWorld(host_lib().rlh_rtc_test_obj_scene(obj_text, len(obj_text), res_x, res_y))
 
     @staticmethod
+    def test_mirror_scene(res_x=300, res_y=200):  # tests/ray_tracer.rs:56-240
+        L = host_lib()
+        L.rlh_rtc_named_scene.restype = C.c_void_p
+        L.rlh_rtc_named_scene.argtypes = [C.c_int, C.c_uint64, C.c_uint64]
+        return RtcWorld(L.rlh_rtc_named_scene(0, res_x, res_y))
+
+    @staticmethod
+    def test_csg_scene(res_x=300, res_y=200):  # tests/ray_tracer.rs:277-368
+        L = host_lib()
+        L.rlh_rtc_named_scene.restype = C.c_void_p
+        L.rlh_rtc_named_scene.argtypes = [C.c_int, C.c_uint64, C.c_uint64]
+        return RtcWorld(L.rlh_rtc_named_scene(1, res_x, res_y))
+
+    @staticmethod
     def from_arrays(triangles, materials, objects, lights, groups=(), group_items=(), boundeds=(), transformeds=(),
-                    max_reflection_depth=5, void_color=(0.0, 0.0, 0.0), camera=None):
+                    max_reflection_depth=5, void_color=(0.0, 0.0, 0.0), camera=None, shapes=(), csgs=(), patterns=()):
         def arr(x, dt):
             return np.zeros(0, dtype=dt) if len(x) == 0 else np.ascontiguousarray(x, dtype=dt)
         arrs = dict(triangles=arr(triangles, RTC_TRIANGLE), groups=arr(groups, RTC_GROUP), group_items=arr(group_items, HREF),
                     boundeds=arr(boundeds, RTC_BOUNDED), transformeds=arr(transformeds, RTC_TRANSFORMED),
-                    materials=arr(materials, RTC_MATERIAL), objects=arr(objects, HREF), lights=arr(lights, RTC_LIGHT))
+                    materials=arr(materials, RTC_MATERIAL), objects=arr(objects, HREF), lights=arr(lights, RTC_LIGHT),
+                    shapes=arr(shapes, RTC_SHAPE), csgs=arr(csgs, RTC_CSG), patterns=arr(patterns, RTC_PATTERN))
         d = RtcSceneDesc()
         for k, a in arrs.items():
             setattr(d, k, a.ctypes.data if len(a) else None)

@@ -321,6 +321,20 @@ rlh_rtc *rlh_rtc_test_obj_scene(const char *obj_text, uint64_t obj_len, uint64_t
     return nullptr;
   }
 }
+// which: 0 = mirror scene, 1 = CSG scene (ray-tracer-challenge/tests/ray_tracer.rs:56, :277)
+rlh_rtc *rlh_rtc_named_scene(int which, uint64_t res_x, uint64_t res_y) {
+  try {
+    auto s = which == 0 ? scenes::rtc_test_mirror_scene(res_x, res_y) : scenes::rtc_test_csg_scene(res_x, res_y);
+    auto *h = new rlh_rtc();
+    s.world.flatten(h->flat);
+    h->desc = h->flat.desc();
+    h->camera = s.camera->derived();
+    return h;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 const rl_rtc_scene_desc *rlh_rtc_desc(const rlh_rtc *h) { return &h->desc; }
 void rlh_rtc_get_camera(const rlh_rtc *h, rl_rtc_camera *out) { *out = h->camera; }
 void rlh_rtc_free(rlh_rtc *h) { delete h; }

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -146,8 +147,14 @@ inline Matrix4 view_transform(const Point3d &from, const Point3d &to, const Vec3
 struct Color {
   double r, g, b;
 };
-struct Material {  // material.rs:22-52 (Surface::Color only on this path)
-  Color surface{1.0, 1.0, 1.0};
+struct Pattern {  // scene/pattern/{stripe,ring,gradient,checker3d}.rs
+  uint32_t kind = 0;  // RL_PAT_*; 0 = none (Surface::Color)
+  Color a{1.0, 1.0, 1.0}, b{0.0, 0.0, 0.0};
+  InvertibleMatrix4 transform = InvertibleMatrix4::identity();
+};
+struct Material {  // material.rs:22-52
+  Color surface{1.0, 1.0, 1.0};  // Surface::Color(..) when pattern.kind == 0
+  Pattern pattern;               // Surface::Pattern(..) otherwise
   double ambient = 0.1, diffuse = 0.9, specular = 0.9, shininess = 200.0;
   double reflectivity = 0.0, transparency = 0.0, refractive_index = 1.0;
 };
@@ -166,10 +173,22 @@ struct Flattened {
   std::vector<rl_rtc_material> materials;
   std::vector<rl_oref> objects;
   std::vector<rl_rtc_light> lights;
+  std::vector<rl_rtc_shape> shapes;
+  std::vector<rl_rtc_csg> csgs;
+  std::vector<rl_rtc_pattern> patterns;
   uint32_t max_reflection_depth = 5;
   double void_color[3] = {0, 0, 0};
   uint32_t add_material(const Material &m) {
     rl_rtc_material r{};
+    if (m.pattern.kind != 0) {
+      rl_rtc_pattern pt{};
+      pt.kind = m.pattern.kind;
+      pt.a[0] = m.pattern.a.r, pt.a[1] = m.pattern.a.g, pt.a[2] = m.pattern.a.b;
+      pt.b[0] = m.pattern.b.r, pt.b[1] = m.pattern.b.g, pt.b[2] = m.pattern.b.b;
+      std::memcpy(pt.inverse, m.pattern.transform.inverse.m, sizeof pt.inverse);
+      patterns.push_back(pt);
+      r.pattern = (uint32_t)patterns.size();  // 1-based
+    }
     r.color[0] = m.surface.r, r.color[1] = m.surface.g, r.color[2] = m.surface.b;
     r.ambient = m.ambient, r.diffuse = m.diffuse, r.specular = m.specular, r.shininess = m.shininess;
     r.reflectivity = m.reflectivity, r.transparency = m.transparency, r.refractive_index = m.refractive_index;
@@ -188,6 +207,9 @@ struct Flattened {
     d.lights = lights.data(), d.n_lights = (uint32_t)lights.size();
     d.max_reflection_depth = max_reflection_depth;
     d.void_color[0] = void_color[0], d.void_color[1] = void_color[1], d.void_color[2] = void_color[2];
+    d.shapes = shapes.data(), d.n_shapes = (uint32_t)shapes.size();
+    d.csgs = csgs.data(), d.n_csgs = (uint32_t)csgs.size();
+    d.patterns = patterns.data(), d.n_patterns = (uint32_t)patterns.size();
     return d;
   }
 };
@@ -251,6 +273,68 @@ struct Triangle : Object {  // object/triangle.rs:22-56
     t.n3[0] = n[2].x, t.n3[1] = n[2].y, t.n3[2] = n[2].z;
     f.triangles.push_back(t);
     return rl_oref{RL_O_TRIANGLE, (uint32_t)f.triangles.size() - 1};
+  }
+};
+
+// analytic shapes (object/{sphere,plane,cube,cylinder,cone}.rs) in their own object space
+struct Shape : Object {
+  uint32_t kind;
+  Material material;
+  bool has_min = false, has_max = false, closed = false;
+  double minimum = 0.0, maximum = 0.0;
+  Shape(uint32_t k, const Material &m) : kind(k), material(m) {}
+  static std::shared_ptr<Shape> sphere(const Material &m = Material{}) { return std::make_shared<Shape>(RL_O_SPHERE, m); }
+  static std::shared_ptr<Shape> plane(const Material &m = Material{}) { return std::make_shared<Shape>(RL_O_PLANE, m); }
+  static std::shared_ptr<Shape> cube(const Material &m = Material{}) { return std::make_shared<Shape>(RL_O_CUBE, m); }
+  static std::shared_ptr<Shape> cylinder(const Material &m, bool hmin, double mn, bool hmax, double mx, bool closed) {
+    auto s = std::make_shared<Shape>(RL_O_CYLINDER, m);
+    s->has_min = hmin, s->minimum = mn, s->has_max = hmax, s->maximum = mx, s->closed = closed;
+    return s;
+  }
+  static std::shared_ptr<Shape> cone(const Material &m, bool hmin, double mn, bool hmax, double mx, bool closed) {
+    auto s = cylinder(m, hmin, mn, hmax, mx, closed);
+    s->kind = RL_O_CONE;
+    return s;
+  }
+  Bounds bounds() const override {
+    const double I = std::numeric_limits<double>::infinity();
+    switch (kind) {
+      case RL_O_PLANE: return Bounds{{-I, -1e8, -I}, {I, 1e8, I}};  // plane.rs:44-50
+      case RL_O_CYLINDER: return Bounds{{-1.0, has_min ? minimum : -I, -1.0}, {1.0, has_max ? maximum : I, 1.0}};
+      case RL_O_CONE: {  // cone.rs:140-150
+        double y_min = has_min ? minimum : -I, y_max = has_max ? maximum : I;
+        double radius = std::fmax(std::fabs(y_max), std::fabs(y_min));
+        return Bounds{{-radius, y_min, -radius}, {radius, y_max, radius}};
+      }
+      default: return Bounds{{-1.0, -1.0, -1.0}, {1.0, 1.0, 1.0}};
+    }
+  }
+  rl_oref flatten(Flattened &f) const override {
+    rl_rtc_shape s{};
+    s.kind = kind;
+    s.material = f.add_material(material);
+    s.has_minimum = has_min, s.has_maximum = has_max, s.closed = closed;
+    s.minimum = minimum, s.maximum = maximum;
+    f.shapes.push_back(s);
+    return rl_oref{kind, (uint32_t)f.shapes.size() - 1};
+  }
+};
+
+struct Csg : Object {  // object/csg.rs:32-36
+  ObjectPtr left, right;
+  uint32_t operation;
+  Csg(ObjectPtr l, ObjectPtr r, uint32_t op) : left(l), right(r), operation(op) {}
+  Bounds bounds() const override {  // Bounds::from_bounds(&[left, right])
+    Bounds a = left->bounds(), b = right->bounds();
+    return Bounds::from_points({a.minimum, a.maximum, b.minimum, b.maximum});
+  }
+  rl_oref flatten(Flattened &f) const override {
+    rl_rtc_csg c{};
+    c.operation = operation;
+    c.left = left->flatten(f);
+    c.right = right->flatten(f);
+    f.csgs.push_back(c);
+    return rl_oref{RL_O_CSG, (uint32_t)f.csgs.size() - 1};
   }
 };
 

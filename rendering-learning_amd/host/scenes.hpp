@@ -397,4 +397,74 @@ inline RtcScene rtc_test_obj_scene(const std::string &teapot_obj_text, size_t re
   return s;
 }
 
+// tests/ray_tracer.rs:56-240 (mirror_scene) and :277-368 (csg_scene)
+inline rtc::InvertibleMatrix4 rtc_xf(const std::vector<rtc::Matrix4> &seq) { return rtc::InvertibleMatrix4::try_from(rtc::transformation::sequence(seq)); }
+
+inline RtcScene rtc_test_mirror_scene(size_t res_x = 300, size_t res_y = 200) {
+  using namespace rtc;
+  namespace T = transformation;
+  const double FRAC_PI_4 = 0.785398163397448309615660845819875721;
+  auto xf = [](ObjectPtr o, const std::vector<Matrix4> &seq) { return std::make_shared<Transformed>(o, rtc_xf(seq)); };
+  auto gs1 = xf(Shape::sphere(), {T::translation(-0.5, 0.0, 0.0)});
+  auto gs2 = xf(Shape::sphere(), {T::translation(0.5, 0.0, 0.0)});
+  ObjectPtr sphere_group = std::make_shared<Bounded>(
+      xf(std::make_shared<Group>(std::vector<ObjectPtr>{gs1, gs2}), {T::rotation_z(FRAC_PI_2), T::translation(-2.0, 2.0, 0.0)}));
+  Material fm;
+  fm.pattern.kind = RL_PAT_CHECKER3D, fm.pattern.a = Color{1, 1, 1}, fm.pattern.b = Color{0, 0, 0};
+  fm.pattern.transform = rtc_xf({T::translation(0.0, -0.01, 0.0)});
+  fm.specular = 0.0, fm.reflectivity = 0.02;
+  ObjectPtr floor = Shape::plane(fm);
+  Material lw;
+  lw.surface = Color{1, 1, 1}, lw.specular = 1.0, lw.reflectivity = 0.9, lw.shininess = 400.0, lw.diffuse = 0.0;
+  ObjectPtr left_wall = xf(Shape::plane(lw), {T::rotation_x(FRAC_PI_2), T::rotation_y(-FRAC_PI_3), T::translation(-8.0, 0.0, 0.0)});
+  Material rw = lw;
+  rw.reflectivity = 1.0;
+  ObjectPtr right_wall = xf(Shape::plane(rw), {T::rotation_x(FRAC_PI_2), T::rotation_y(FRAC_PI_4), T::translation(10.0, 0.0, 0.0)});
+  Material mw;
+  mw.surface = Color{0.945, 0.788, 0.647}, mw.specular = 0.1, mw.shininess = 50.0;
+  ObjectPtr middle_wall = xf(Shape::plane(mw), {T::rotation_x(FRAC_PI_2), T::translation(0.0, 0.0, 7.0)});
+  Material bm;
+  bm.surface = Color{0.059, 0.322, 0.729}, bm.diffuse = 0.3, bm.specular = 1.0, bm.reflectivity = 0.9, bm.transparency = 0.75, bm.refractive_index = 1.52;
+  ObjectPtr ball = xf(Shape::sphere(bm), {T::translation(0.0, 2.0, 0.0)});
+  Material am;
+  am.surface = Color{1, 1, 1}, am.ambient = 0.0, am.diffuse = 0.0, am.specular = 0.0, am.transparency = 1.0, am.refractive_index = 1.0, am.reflectivity = 1.0;
+  ObjectPtr inner_air_pocket = xf(Shape::sphere(am), {T::scaling(0.5, 0.5, 0.5), T::translation(0.0, 2.0, 0.0)});
+  Material cm;
+  cm.pattern.kind = RL_PAT_STRIPE, cm.pattern.a = Color{0.545, 0.0, 0.0}, cm.pattern.b = Color{0.0, 0.392, 0.0};
+  cm.pattern.transform = rtc_xf({T::scaling(0.2, 1.0, 1.0)});
+  ObjectPtr behind_cube = xf(Shape::cube(cm), {T::translation(3.0, 0.0, -10.0)});
+  Material bw;
+  bw.surface = Color{0.678, 0.847, 0.902}, bw.specular = 0.1, bw.shininess = 50.0;
+  ObjectPtr behind_wall = xf(Shape::plane(bw), {T::rotation_x(FRAC_PI_2), T::translation(0.0, 0.0, -100.0)});
+  RtcScene s;
+  s.world.objects = {floor, left_wall, right_wall, middle_wall, ball, inner_air_pocket, behind_cube, behind_wall, sphere_group};
+  s.world.lights.push_back(PointLight{Point3d{-10.0, 10.0, -10.0}, Color{1.0, 1.0, 1.0}});
+  s.camera = std::make_shared<Camera>(res_x, res_y, FRAC_PI_3,
+                                      InvertibleMatrix4::try_from(T::view_transform(Point3d{0.0, 2.0, -7.0}, Point3d{0.0, 1.5, 0.0}, Vec3d{0.0, 1.0, 0.0})));
+  return s;
+}
+
+inline RtcScene rtc_test_csg_scene(size_t res_x = 300, size_t res_y = 200) {
+  using namespace rtc;
+  namespace T = transformation;
+  auto xf = [](ObjectPtr o, const std::vector<Matrix4> &seq) { return std::make_shared<Transformed>(o, rtc_xf(seq)); };
+  Material rm;
+  rm.pattern.kind = RL_PAT_CHECKER3D, rm.pattern.a = Color{0.6, 0.6, 0.6}, rm.pattern.b = Color{0.7, 0.7, 0.7};
+  rm.pattern.transform = rtc_xf({T::translation(0.01, 0.01, 0.01), T::scaling(0.02, 0.02, 0.02)});
+  rm.reflectivity = 0.0, rm.ambient = 0.5, rm.shininess = 10.0, rm.diffuse = 0.3, rm.specular = 0.3;
+  ObjectPtr room = xf(Shape::cube(rm), {T::scaling(50.0, 50.0, 50.0)});
+  Material g, b, r;
+  g.surface = Color{0, 1, 0}, b.surface = Color{0, 0, 1}, r.surface = Color{1, 0, 0};
+  ObjectPtr hollow = std::make_shared<Csg>(Shape::sphere(g), xf(Shape::sphere(b), {T::scaling(0.7, 0.7, 0.7)}), RL_CSG_DIFFERENCE);
+  ObjectPtr object = std::make_shared<Csg>(hollow, xf(Shape::cube(r), {T::translation(1.0, 0.0, 0.0)}), RL_CSG_DIFFERENCE);
+  ObjectPtr object_t = xf(object, {T::rotation_y(FRAC_PI_6), T::scaling(7.0, 7.0, 7.0)});
+  RtcScene s;
+  s.world.objects = {room, object_t};
+  s.world.lights.push_back(PointLight{Point3d{-2.0, 20.0, -30.0}, Color{0.5, 0.5, 0.5}});
+  s.world.lights.push_back(PointLight{Point3d{10.0, 20.0, -30.0}, Color{0.5, 0.5, 0.5}});
+  s.camera = std::make_shared<Camera>(res_x, res_y, FRAC_PI_3,
+                                      InvertibleMatrix4::try_from(T::view_transform(Point3d{0.0, 0.0, -30.0}, Point3d{0.0, 0.0, 0.0}, Vec3d{0.0, 1.0, 0.0})));
+  return s;
+}
+
 }  // namespace scenes
