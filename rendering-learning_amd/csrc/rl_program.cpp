@@ -279,8 +279,9 @@ struct RtcCompiler {
   const rl_rtc_scene_desc &d;
   RtcProgram &p;
   std::string &err;
-  std::vector<uint8_t> g_busy, b_busy, t_busy;
+  std::vector<uint8_t> g_busy, b_busy, t_busy, c_busy;
   std::vector<uint32_t> enter_stack;
+  uint32_t csg_depth = 0;
   bool fail(const std::string &m) {
     err = m;
     return false;
@@ -291,6 +292,14 @@ struct RtcCompiler {
       case RL_O_GROUP: return o.index < d.n_groups || fail("group index out of range");
       case RL_O_BOUNDED: return o.index < d.n_boundeds || fail("bounded index out of range");
       case RL_O_TRANSFORMED: return o.index < d.n_transformeds || fail("transformed index out of range");
+      case RL_O_SPHERE:
+      case RL_O_PLANE:
+      case RL_O_CUBE:
+      case RL_O_CYLINDER:
+      case RL_O_CONE:
+        if (o.index >= d.n_shapes) return fail("shape index out of range");
+        return d.shapes[o.index].kind == o.kind || fail("shape kind does not match its reference");
+      case RL_O_CSG: return o.index < d.n_csgs || fail("csg index out of range");
       default: return fail("unknown object kind");
     }
   }
@@ -310,6 +319,41 @@ struct RtcCompiler {
       case RL_O_TRIANGLE:
         emit_tri(o.index);
         return true;
+      case RL_O_SPHERE:
+      case RL_O_PLANE:
+      case RL_O_CUBE:
+      case RL_O_CYLINDER:
+      case RL_O_CONE: {
+        DevOp op{};
+        op.code = ROP_SHAPE, op.a = o.index;
+        p.ops.push_back(op);
+        p.needs_full = true;
+        return true;
+      }
+      case RL_O_CSG: {
+        if (c_busy[o.index]) return fail("cycle through a csg");
+        const rl_rtc_csg &c = d.csgs[o.index];
+        if (c.operation > RL_CSG_DIFFERENCE) return fail("unknown csg operation");
+        c_busy[o.index] = 1;
+        csg_depth++;
+        if (csg_depth > p.max_csg_depth) p.max_csg_depth = csg_depth;
+        if (csg_depth > 4) return fail("CSG nesting deeper than 4");
+        DevOp op{};
+        op.code = ROP_CSG_BEGIN, op.a = o.index;
+        p.ops.push_back(op);
+        if (!emit(c.left, depth + 1)) return false;
+        DevOp mid{};
+        mid.code = ROP_CSG_MID, mid.a = o.index;
+        p.ops.push_back(mid);
+        if (!emit(c.right, depth + 1)) return false;
+        DevOp end{};
+        end.code = ROP_CSG_END, end.a = o.index;
+        p.ops.push_back(end);
+        csg_depth--;
+        c_busy[o.index] = 0;
+        p.needs_full = true;
+        return true;
+      }
       case RL_O_GROUP: {
         if (g_busy[o.index]) return fail("cycle through a group");
         const rl_rtc_group &g = d.groups[o.index];
@@ -387,11 +431,33 @@ int compile_rtc(const rl_rtc_scene_desc &d, RtcProgram &p, std::string &err) {
   p.xforms.assign(d.transformeds, d.transformeds + d.n_transformeds);
   p.materials.assign(d.materials, d.materials + d.n_materials);
   p.lights.assign(d.lights, d.lights + d.n_lights);
-  for (const auto &m : p.materials)
+  if (!need(d.shapes, d.n_shapes, "shapes") || !need(d.csgs, d.n_csgs, "csgs") || !need(d.patterns, d.n_patterns, "patterns")) return RL_E_INVALID;
+  p.shapes.assign(d.shapes, d.shapes + d.n_shapes);
+  p.csgs.assign(d.csgs, d.csgs + d.n_csgs);
+  p.patterns.assign(d.patterns, d.patterns + d.n_patterns);
+  for (const auto &sh : p.shapes)
+    if (sh.material >= d.n_materials) {
+      err = "shape material out of range";
+      return RL_E_INVALID;
+    }
+  for (const auto &pt : p.patterns)
+    if (pt.kind < RL_PAT_STRIPE || pt.kind > RL_PAT_CHECKER3D) {
+      err = "unknown pattern kind";
+      return RL_E_INVALID;
+    }
+  for (const auto &m : p.materials) {
     if (m.reflectivity != 0.0 || m.transparency != 0.0) p.needs_secondary = true;
+    if (m.pattern > d.n_patterns) {
+      err = "material pattern out of range";
+      return RL_E_INVALID;
+    }
+    if (m.pattern != 0) p.needs_full = true;
+  }
+  if (p.needs_secondary) p.needs_full = true;
   p.max_reflection_depth = d.max_reflection_depth;
   std::memcpy(p.void_color, d.void_color, 24);
-  RtcCompiler c{d, p, err, std::vector<uint8_t>(d.n_groups, 0), std::vector<uint8_t>(d.n_boundeds, 0), std::vector<uint8_t>(d.n_transformeds, 0)};
+  RtcCompiler c{d, p, err, std::vector<uint8_t>(d.n_groups, 0), std::vector<uint8_t>(d.n_boundeds, 0), std::vector<uint8_t>(d.n_transformeds, 0),
+                std::vector<uint8_t>(d.n_csgs, 0)};
   for (uint32_t i = 0; i < d.n_objects; i++)
     if (!c.emit(d.objects[i], 0)) return RL_E_INVALID;
   DevOp end{};

@@ -95,6 +95,10 @@ enum : uint32_t {
   ROP_EXIT = 2,    // a = transformed index
   ROP_BOUNDS = 3,  // Bounded: box test (tmin <= tmax); miss -> pc = skip
   ROP_TRIS = 4,    // triangles [a, a+b)
+  ROP_SHAPE = 5,   // analytic shape a (sphere / plane / cube / cylinder / cone)
+  ROP_CSG_BEGIN = 6,  // a = csg index; children follow: left ops, ROP_CSG_MID, right ops, ROP_CSG_END
+  ROP_CSG_MID = 7,
+  ROP_CSG_END = 8,    // a = csg index
 };
 
 struct alignas(16) DevTri {  // 160 B
@@ -115,6 +119,11 @@ struct RtcProgram {
   double void_color[3] = {0, 0, 0};
   uint32_t max_xform_depth = 0;
   bool needs_secondary = false;  // any reflective / transparent material
+  bool needs_full = false;       // shapes / CSG / patterns / secondary rays: the full color_at kernel
+  std::vector<rl_rtc_shape> shapes;
+  std::vector<rl_rtc_csg> csgs;
+  std::vector<rl_rtc_pattern> patterns;
+  uint32_t max_csg_depth = 0;
 };
 int compile_rtc(const rl_rtc_scene_desc &d, RtcProgram &out, std::string &err);
 

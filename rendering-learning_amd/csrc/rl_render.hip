@@ -13,6 +13,7 @@
 
 #include "rl_program.h"
 #include "rl_rtc_kernel.h"
+#include "rl_rtc_full_kernel.h"
 #include "rl_rtiow_kernel.h"
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
@@ -74,6 +75,9 @@ struct rl_scene {
   rl_rtc_transformed *d_xforms = nullptr;
   rl_rtc_material *d_rmaterials = nullptr;
   rl_rtc_light *d_lights = nullptr;
+  rl_rtc_shape *d_shapes = nullptr;
+  rl_rtc_csg *d_csgs = nullptr;
+  rl_rtc_pattern *d_patterns = nullptr;
   // per-scene scratch: [0] work counter (u32), [8..] 8 x u64 stats
   unsigned char *d_scratch = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -146,6 +150,7 @@ void rl_scene_destroy(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns);
   hipFree(s->wf_pix), hipFree(s->wf_ray), hipFree(s->wf_hit), hipFree(s->wf_qtrav), hipFree(s->wf_qshade), hipFree(s->wf_qgen), hipFree(s->wf_ctl), hipFree(s->wf_class);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -510,14 +515,15 @@ rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
     delete s;
     return nullptr;
   }
-  if (s->rc.needs_secondary) {
-    set_err(RL_E_UNSUPPORTED, "reflective / transparent materials (recursive color_at) have no gfx950 kernel yet in this build");
+  if (s->rc.lights.size() > 0xFFFFu) {
+    set_err(RL_E_UNSUPPORTED, "too many lights");
     delete s;
     return nullptr;
   }
   int rc = RL_OK;
   if ((rc = upload(s->rc.ops, &s->d_ops)) || (rc = upload(s->rc.tris, &s->d_tris)) || (rc = upload(s->rc.xforms, &s->d_xforms)) ||
-      (rc = upload(s->rc.materials, &s->d_rmaterials)) || (rc = upload(s->rc.lights, &s->d_lights)) || (rc = scene_common(s))) {
+      (rc = upload(s->rc.materials, &s->d_rmaterials)) || (rc = upload(s->rc.lights, &s->d_lights)) || (rc = upload(s->rc.shapes, &s->d_shapes)) ||
+      (rc = upload(s->rc.csgs, &s->d_csgs)) || (rc = upload(s->rc.patterns, &s->d_patterns)) || (rc = scene_common(s))) {
     rl_scene_destroy(s);
     return nullptr;
   }
@@ -556,7 +562,13 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
   uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
   bool want_stats = st != nullptr;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
-  if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
+  if (scene->rc.needs_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
+    RtcFullParams F{};
+    F.R = P;
+    F.shapes = scene->d_shapes, F.csgs = scene->d_csgs, F.patterns = scene->d_patterns;
+    F.n_tris = P.n_tris, F.max_reflection_depth = scene->rc.max_reflection_depth;
+    hipLaunchKernelGGL((rtc_full_kernel<NT>), dim3(blocks), dim3(NT), 0, stream, F);
+  } else if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
   else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
   HIP_TRY(hipGetLastError());
   if (want_stats) {
