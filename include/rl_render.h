@@ -204,6 +204,12 @@ int rl_rtiow_render_device(const rl_scene *, const rl_rtiow_camera *, uint64_t f
                            uint32_t row_first, uint32_t row_step, void *d_out_rgb_sum,
                            void *hip_stream, rl_stats *opt_stats);
 
+/* Output stage on the device (color.rs:22-57, output.rs:5-14): mean = sum * (1/samples), linear_to_srgb,
+ * floor(v * 255.999) clamped to 0..255.  d_rgb_sum / d_rgb8 are DEVICE pointers (n_pixels*3 f64 / u8). */
+int rl_rtiow_encode_rgb8_device(const void *d_rgb_sum, uint64_t n_pixels, uint32_t samples, void *d_rgb8, void *hip_stream);
+/* Render + encode on the device, copy back only the W*H*3 bytes a P3 PPM prints (24x less PCIe traffic). */
+int rl_rtiow_render_rgb8(const rl_scene *, const rl_rtiow_camera *, uint64_t first_sample, uint8_t *out_rgb8, rl_stats *opt_stats);
+
 /* =====================================================================
  *  RTC  (ray-tracer-challenge)
  * ===================================================================== */
@@ -320,6 +326,10 @@ int rl_rtc_render_rows(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samp
 int rl_rtc_render_device(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samples,
                          uint32_t row_first, uint32_t row_step, void *d_out_rgb, void *hip_stream,
                          rl_stats *opt_stats);
+
+/* Output stage on the device (draw/canvas.rs:53-56): round(c * 255) (half away from zero) clamped to 0..255. */
+int rl_rtc_encode_rgb8_device(const void *d_rgb, uint64_t n_pixels, void *d_rgb8, void *hip_stream);
+int rl_rtc_render_rgb8(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samples, uint8_t *out_rgb8, rl_stats *opt_stats);
 
 #ifdef __cplusplus
 }

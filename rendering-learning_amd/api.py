@@ -147,7 +147,9 @@ def host_lib():
 # every symbol include/rl_render.h declares (checked by tests/test_abi.py)
 RENDER_SYMBOLS = ["rl_init", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info", "rl_scene_destroy",
                   "rl_rtiow_scene_create", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
-                  "rl_rtc_scene_create", "rl_rtc_render", "rl_rtc_render_rows", "rl_rtc_render_device"]
+                  "rl_rtiow_encode_rgb8_device", "rl_rtiow_render_rgb8",
+                  "rl_rtc_scene_create", "rl_rtc_render", "rl_rtc_render_rows", "rl_rtc_render_device",
+                  "rl_rtc_encode_rgb8_device", "rl_rtc_render_rgb8"]
 
 
 def render_lib():
@@ -169,6 +171,10 @@ def render_lib():
         L.rl_rtiow_render.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtiow_render_rows.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtiow_render_device.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_render_rgb8.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_encode_rgb8_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rl_rtc_render_rgb8.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_encode_rgb8_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rl_rtc_render.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtc_render_rows.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtc_render_device.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
@@ -435,6 +441,33 @@ class Canvas:  # camera.rs:263-296; data = SUMS over samples, [H, W, 3] f64
     def pixel_data(self):  # camera.rs:293: c / samples == c * (1/samples)
         return self.data * (1.0 / self.samples)
 
+    def to_bincode(self) -> bytes:
+        """The reference's checkpoint bytes: bincode::serialize(&canvas) (examples/common/mod.rs:32)."""
+        L = host_lib()
+        L.rlh_canvas_to_bincode.restype = C.c_void_p
+        L.rlh_canvas_to_bincode.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        d = np.ascontiguousarray(self.data, dtype=np.float64)
+        n = C.c_uint64()
+        p = L.rlh_canvas_to_bincode(self.samples, self.width, self.height, d.ctypes.data, d.size // 3, C.byref(n))
+        b = C.string_at(p, n.value)
+        L.rlh_free(p)
+        return b
+
+    @staticmethod
+    def from_bincode(b: bytes):
+        """bincode::deserialize::<Canvas> (examples/common/mod.rs:45-46)."""
+        L = host_lib()
+        L.rlh_canvas_from_bincode.argtypes = [C.c_char_p, C.c_uint64] + [C.POINTER(C.c_uint64)] * 4
+        s, w, h, n = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        if L.rlh_canvas_from_bincode(b, len(b), C.byref(s), C.byref(w), C.byref(h), C.byref(n)) != 0:
+            raise ValueError("malformed checkpoint: " + L.rlh_last_error().decode())
+        data = np.frombuffer(b, dtype="<f8", offset=32, count=n.value * 3).copy()
+        if n.value == w.value * h.value:
+            data = data.reshape(h.value, w.value, 3)
+        else:
+            data = data.reshape(-1, 3)
+        return Canvas(s.value, w.value, h.value, data)
+
 
 class Camera:
     def __init__(self, params: CameraParams):  # Camera::new camera.rs:72
@@ -459,6 +492,12 @@ class Camera:
     def render(self, world: World, stats=None, allow_degenerate=False) -> Canvas:  # camera.rs:122
         data = self._render(0, world, stats=stats, allow_degenerate=allow_degenerate)
         return Canvas(self.params.samples_per_pixel, self.c.image_width, self.c.image_height, data)
+
+    def render_rgb8(self, world: World) -> np.ndarray:
+        """render + the device output stage (sRGB, floor(v*255.999)): the [H, W, 3] bytes output_ppm prints."""
+        out = np.empty((self.c.image_height, self.c.image_width, 3), dtype=np.uint8)
+        _check(render_lib().rl_rtiow_render_rgb8(world.device(), C.byref(self.c), 0, out.ctypes.data, None), allow_degenerate=True)
+        return out
 
     def render_from_checkpoint(self, world: World, checkpoint: Canvas) -> Canvas:  # camera.rs:136-143
         data = self._render(checkpoint.samples, world)
@@ -579,6 +618,13 @@ class RtcWorld:
         if stats is not None:
             stats.update(st.as_dict())
             stats["rc"] = rc
+        return out
+
+    def render_rgb8(self, aa_samples=1, camera=None) -> np.ndarray:
+        """render + the device output stage (round(c*255)): the [H, W, 3] bytes Canvas::ppm prints."""
+        cam = camera or self.camera
+        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.uint8)
+        _check(render_lib().rl_rtc_render_rgb8(self.device(), C.byref(cam), aa_samples, out.ctypes.data, None), allow_degenerate=True)
         return out
 
     def render_device(self, d_ptr, aa_samples=1, camera=None, stream=0, row_first=0, row_step=1, stats=None):

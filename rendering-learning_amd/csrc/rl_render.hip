@@ -53,6 +53,24 @@ int upload(const std::vector<T> &v, T **out) {
   return RL_OK;
 }
 
+// Output stages
+__global__ void encode_rtiow_rgb8(const double *sum, unsigned long long n_vals, double inv_samples, unsigned char *out) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_vals) return;
+  double v = sum[i] * inv_samples;                                                 // camera.rs:293
+  double s = v <= 0.0031308 ? 12.92 * v : (1.0 + 0.055) * pow(v, 1.0 / 2.4) - 0.055;  // color.rs:130-136
+  double f = floor(s * 255.999);                                                   // color.rs:47-50 (as i16 saturates; NaN -> 0)
+  int q = isnan(f) ? 0 : (f >= 32767.0 ? 32767 : (f <= -32768.0 ? -32768 : (int)f));
+  out[i] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+__global__ void encode_rtc_rgb8(const double *rgb, unsigned long long n_vals, unsigned char *out) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_vals) return;
+  double v = round(rgb[i] * 255.0);  // canvas.rs:53-56: f64::round = half away from zero; as i32 saturates
+  int q = isnan(v) ? 0 : (v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (int)-2147483648LL : (int)v));
+  out[i] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
+}
+
 }  // namespace
 
 struct rl_scene {
@@ -493,6 +511,46 @@ int rl_rtiow_render_rows(const rl_scene *scene, const rl_rtiow_camera *cam, uint
   return rc;
 }
 
+int rl_rtiow_encode_rgb8_device(const void *d_rgb_sum, uint64_t n_pixels, uint32_t samples, void *d_rgb8, void *hip_stream) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!d_rgb_sum || !d_rgb8 || samples == 0) return set_err(RL_E_INVALID, "bad argument");
+  unsigned long long n = n_pixels * 3ull;
+  if (n == 0) return RL_OK;
+  hipLaunchKernelGGL(encode_rtiow_rgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (const double *)d_rgb_sum, n,
+                     1.0 / (double)samples, (unsigned char *)d_rgb8);
+  HIP_TRY(hipGetLastError());
+  return RL_OK;
+}
+
+int rl_rtiow_render_rgb8(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint8_t *out, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || !cam || !out) return set_err(RL_E_INVALID, "bad argument");
+  size_t npix = (size_t)cam->image_width * cam->image_height;
+  if (npix == 0 || cam->samples_per_pixel == 0) return set_err(RL_E_INVALID, "empty image / zero samples");
+  double *d_sum = nullptr;
+  unsigned char *d_u8 = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_sum, npix * 3 * sizeof(double)));
+  hipError_t e = hipMalloc((void **)&d_u8, npix * 3);
+  if (e != hipSuccess) {
+    hipFree(d_sum);
+    return set_err(RL_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  rl_stats local;
+  int rc = rl_rtiow_render_device(scene, cam, first_sample, 0, 1, d_sum, g_stream, &local);
+  if (rc == RL_OK || rc == RL_E_DEGENERATE) {
+    int rc2 = rl_rtiow_encode_rgb8_device(d_sum, npix, cam->samples_per_pixel, d_u8, g_stream);
+    if (rc2 != RL_OK) rc = rc2;
+    else {
+      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, g_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+      if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("D2H: ") + hipGetErrorString(e));
+    }
+  }
+  hipFree(d_sum), hipFree(d_u8);
+  if (st) *st = local;
+  return rc;
+}
+
 int rl_rtiow_render(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, double *out, rl_stats *st) {
   return rl_rtiow_render_rows(scene, cam, first_sample, 0, 1, out, st);
 }
@@ -604,6 +662,45 @@ int rl_rtc_render_rows(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t
     if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
   }
   hipFree(d_out);
+  if (st) *st = local;
+  return rc;
+}
+
+int rl_rtc_encode_rgb8_device(const void *d_rgb, uint64_t n_pixels, void *d_rgb8, void *hip_stream) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!d_rgb || !d_rgb8) return set_err(RL_E_INVALID, "bad argument");
+  unsigned long long n = n_pixels * 3ull;
+  if (n == 0) return RL_OK;
+  hipLaunchKernelGGL(encode_rtc_rgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (const double *)d_rgb, n, (unsigned char *)d_rgb8);
+  HIP_TRY(hipGetLastError());
+  return RL_OK;
+}
+
+int rl_rtc_render_rgb8(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint8_t *out, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || !cam || !out) return set_err(RL_E_INVALID, "bad argument");
+  size_t npix = (size_t)cam->hsize * cam->vsize;
+  if (npix == 0) return set_err(RL_E_INVALID, "empty image");
+  double *d_rgb = nullptr;
+  unsigned char *d_u8 = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_rgb, npix * 3 * sizeof(double)));
+  hipError_t e = hipMalloc((void **)&d_u8, npix * 3);
+  if (e != hipSuccess) {
+    hipFree(d_rgb);
+    return set_err(RL_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  rl_stats local;
+  int rc = rl_rtc_render_device(scene, cam, aa, 0, 1, d_rgb, g_stream, &local);
+  if (rc == RL_OK || rc == RL_E_DEGENERATE) {
+    int rc2 = rl_rtc_encode_rgb8_device(d_rgb, npix, d_u8, g_stream);
+    if (rc2 != RL_OK) rc = rc2;
+    else {
+      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, g_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+      if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("D2H: ") + hipGetErrorString(e));
+    }
+  }
+  hipFree(d_rgb), hipFree(d_u8);
   if (st) *st = local;
   return rc;
 }

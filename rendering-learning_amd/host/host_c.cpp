@@ -301,6 +301,27 @@ char *rlh_rtiow_output_ppm(const double *rgb_sum, uint64_t w, uint64_t h, uint64
   return dup_string(rtiow::output_ppm(rgb_sum, w, h, samples), len);
 }
 
+// Canvas checkpoint codec (bincode 1.x layout of camera.rs:263-270). encode: returns malloc'd bytes (rlh_free).
+void *rlh_canvas_to_bincode(uint64_t samples, uint64_t width, uint64_t height, const double *rgb_sum, uint64_t n_pixels, uint64_t *len) {
+  rtiow::Canvas c{(size_t)samples, (size_t)width, (size_t)height, std::vector<double>(rgb_sum, rgb_sum + n_pixels * 3)};
+  std::vector<uint8_t> b = rtiow::canvas_to_bincode(c);
+  void *p = std::malloc(b.size() ? b.size() : 1);
+  std::memcpy(p, b.data(), b.size());
+  *len = b.size();
+  return p;
+}
+// decode header: returns 0 and fills samples/width/height/n_pixels, or -1 (malformed); pixels start at byte 32
+int rlh_canvas_from_bincode(const uint8_t *bytes, uint64_t len, uint64_t *samples, uint64_t *width, uint64_t *height, uint64_t *n_pixels) {
+  try {
+    rtiow::Canvas c = rtiow::canvas_from_bincode(bytes, (size_t)len);
+    *samples = c.samples, *width = c.width, *height = c.height, *n_pixels = c.data.size() / 3;
+    return 0;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // ------------------------------------------------------------------ RTC
 struct rlh_rtc {
   rtc::Flattened flat;

@@ -575,6 +575,26 @@ struct Canvas {  // camera.rs:263-296: data holds SUMS over samples
   }
 };
 
+// Checkpoint codec (examples/common/mod.rs:23-71): `bincode::serialize(&canvas)` with bincode 1.3.3 defaults —
+// little-endian, fixed-width integers: u64 samples, u64 width, u64 height, u64 data.len(), then len x [f64; 3]
+// (Color is a newtype over [f64; 3]: no per-element length).
+inline std::vector<uint8_t> canvas_to_bincode(const Canvas &c) {
+  std::vector<uint8_t> out(32 + c.data.size() * 8);
+  uint64_t hdr[4] = {(uint64_t)c.samples, (uint64_t)c.width, (uint64_t)c.height, (uint64_t)(c.data.size() / 3)};
+  std::memcpy(out.data(), hdr, 32);
+  if (!c.data.empty()) std::memcpy(out.data() + 32, c.data.data(), c.data.size() * 8);
+  return out;
+}
+inline Canvas canvas_from_bincode(const uint8_t *bytes, size_t len) {
+  if (len < 32) throw std::runtime_error("checkpoint too short");
+  uint64_t hdr[4];
+  std::memcpy(hdr, bytes, 32);
+  if (hdr[3] > (len - 32) / 24 || 32 + hdr[3] * 24 != len) throw std::runtime_error("checkpoint length does not match its pixel count");
+  Canvas c{(size_t)hdr[0], (size_t)hdr[1], (size_t)hdr[2], std::vector<double>((size_t)hdr[3] * 3)};
+  if (hdr[3]) std::memcpy(c.data.data(), bytes + 32, (size_t)hdr[3] * 24);
+  return c;
+}
+
 struct Camera {
   CameraParams params;
   size_t image_height;

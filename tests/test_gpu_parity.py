@@ -161,3 +161,14 @@ def test_rtiow_cost_sorted_two_phase_render_is_bit_identical(rl, oracle):
     cs = {}
     cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
     _assert_rtiow_parity(a, cpu, p.samples_per_pixel, gs, cs)
+
+
+def test_device_output_stage_matches_golden_bytes(rl, golden):
+    # pixel_data / linear_to_srgb / floor(v*255.999) (RTIOW) and round(c*255) (RTC) on the GPU
+    world = rl.World.golden_test_scene()
+    rgb8 = rl.Camera(world.params).render_rgb8(world)
+    want = np.array(golden("test.ppm.gz").split()[4:], dtype=np.uint8).reshape(168, 300, 3)
+    assert np.array_equal(rgb8, want)
+    rw = rl.RtcWorld.test_obj_scene(golden("teapot-low.obj"), 300, 200)
+    want = np.array(golden("test_obj_scene.ppm.gz").split()[4:], dtype=np.uint8).reshape(200, 300, 3)
+    assert np.array_equal(rw.render_rgb8(1), want)
