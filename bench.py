@@ -128,6 +128,7 @@ def main():
         # algorithmic bytes per launch on rank 0's kernel (per-rank share for N>1)
         alg_bytes = (64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 208.0 * st["rays"])
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        launches = 2 if (args.spp >= 64 and os.environ.get("RL_LPT", "1") != "0") else 1
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world_size == 1 and not args.emulate_shard:
@@ -148,6 +149,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "rtiow_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # spp >= 64: one render = two launches of the same kernel (8-sample cost probe + cost-sorted remainder);
+                         # kernel_ms spans both, so rocprofv3's per-launch average = kernel_ms / launches_per_step
+                         "launches_per_step": launches, "kernel_avg_launch_ms": kernel_ms / launches,
                          "note": "scene is LDS-resident: real HBM traffic is the framebuffer; practical ceiling is FP64 VALU issue under divergence"},
         }
         if args.emulate_shard > 1:
