@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +79,8 @@ struct rl_scene {
   // RTIOW
   RtiowProgram rt;
   DevOp *d_ops = nullptr;
+  DevOp *d_lops = nullptr;  // linked form of the ops for the wave kernel (sphere-only scenes)
+  uint32_t entry0 = 0;
   DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
   DevPlanar *d_planars = nullptr;
@@ -164,7 +167,7 @@ int rl_device_info(char *name, int cap) {
 
 void rl_scene_destroy(rl_scene *s) {
   if (!s) return;
-  hipFree(s->d_ops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
+  hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
@@ -181,6 +184,32 @@ static int scene_common(rl_scene *s) {
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   return RL_OK;
+}
+
+// Linked form of a sphere-only program for the wave kernel: every op keeps its box and a, b, but {code, skip}
+// become {w_hit, w_miss} = (state the lane enters there) << 29 | (op index): BOX hit -> op i+1, BOX_SPH hit ->
+// the same op in LEAF, miss / leaf done -> op `skip`; a target that is OP_END means "SHADE", a bare OP_SPHERE
+// "LEAF".  Boxes that are not BOX_FINITE are stored as NaN so the filtered test can never call them certain.
+static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out) {
+  auto entry = [&](uint32_t t) -> uint32_t {
+    uint32_t kind = ops[t].code & 0xFFu;
+    uint32_t st = kind == OP_END ? ST_SHADE : (kind == OP_SPHERE ? ST_LEAF : ST_TRAV);
+    return (st << 29) | t;
+  };
+  out = ops;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  for (size_t i = 0; i < ops.size(); i++) {
+    uint32_t kind = ops[i].code & 0xFFu;
+    if (kind == OP_END) continue;
+    DevOp &L = out[i];
+    L.skip = entry(ops[i].skip);
+    if (kind == OP_BOX) L.code = entry((uint32_t)i + 1u);
+    else if (kind == OP_BOX_SPH) L.code = (ST_LEAF << 29) | (uint32_t)i;
+    else L.code = L.skip;  // OP_SPHERE: never stepped in TRAV
+    if ((kind == OP_BOX || kind == OP_BOX_SPH) && !(ops[i].code & BOX_FINITE))
+      for (double &b : L.box) b = qnan;
+  }
+  return ops.empty() ? (uint32_t)(ST_SHADE << 29) : entry(0);
 }
 
 rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
@@ -224,6 +253,14 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
       (rc = upload(s->rt.image_pool, &s->d_image_pool)) || (rc = scene_common(s))) {
     rl_scene_destroy(s);
     return nullptr;
+  }
+  if (!(s->rt.has_planars || s->rt.has_instances || s->rt.has_images) && s->rt.ops.size() < (1u << 29)) {
+    std::vector<DevOp> lops;
+    s->entry0 = link_ops(s->rt.ops, lops);
+    if (upload(lops, &s->d_lops) != RL_OK) {
+      rl_scene_destroy(s);
+      return nullptr;
+    }
   }
   return s;
 }
@@ -340,6 +377,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
   P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool;
   P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
+  P.lops = scene->d_lops, P.entry0 = scene->entry0;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;

@@ -24,6 +24,8 @@ struct RtiowParams {
   const DevImage *images;
   const float *image_pool;
   uint32_t n_ops, n_spheres;
+  const DevOp *lops;  // wave kernel: ops with {code, skip} replaced by linked successor words (state << 29 | op index), see link_ops
+  uint32_t entry0;    // linked word of op 0: where (and in which state) a new ray starts
   rl_rtiow_camera cam;
   uint32_t key[8];
   uint64_t first_sample;

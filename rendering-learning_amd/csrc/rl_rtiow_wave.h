@@ -129,22 +129,32 @@ template <int NT, bool LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  unsigned long long *s_rng = (unsigned long long *)smem;  // [16][NT]
-  const DevOp *ops = P.ops;
+  // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
+  const size_t scene_lds = LDS_SCENE ? ((size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere)) : 0;
+  unsigned long long *s_rng = (unsigned long long *)(smem + scene_lds);  // [16][NT]
+  const unsigned char *opbase = (const unsigned char *)P.lops;  // pc is an index (HBM) or a byte offset (LDS) into this
   const DevSphere *spheres = P.spheres;
   if (LDS_SCENE) {
-    DevOp *s_ops = (DevOp *)(smem + (size_t)16 * NT * sizeof(unsigned long long));
+    DevOp *s_ops = (DevOp *)smem;
     DevSphere *s_sph = (DevSphere *)(s_ops + P.n_ops);
-    const uint4 *g = (const uint4 *)P.ops;
+    const uint4 *g = (const uint4 *)P.lops;
     uint4 *l = (uint4 *)s_ops;
-    for (uint32_t i = tid; i < P.n_ops * 4u; i += NT) l[i] = g[i];
+    for (uint32_t i = tid; i < P.n_ops * 4u; i += NT) {
+      uint4 v = g[i];
+      if ((i & 3u) == 3u) {  // {w_hit, w_miss, a, b}: successor indices -> LDS byte offsets
+        v.x = (v.x & 0xE0000000u) | ((v.x & 0x1FFFFFFFu) << 6);
+        v.y = (v.y & 0xE0000000u) | ((v.y & 0x1FFFFFFFu) << 6);
+      }
+      l[i] = v;
+    }
     g = (const uint4 *)P.spheres;
     l = (uint4 *)s_sph;
     for (uint32_t i = tid; i < P.n_spheres * 4u; i += NT) l[i] = g[i];
     __syncthreads();
-    ops = s_ops;
+    opbase = smem;
     spheres = s_sph;
   }
+  const uint32_t entry0 = LDS_SCENE ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6)) : P.entry0;
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
   const uint32_t s_begin = P.sample_begin, spp = P.sample_end;  // this launch renders samples [s_begin, spp) of every pixel
@@ -167,6 +177,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
 
   unsigned long long sc_exec[6] = {0, 0, 0, 0, 0, 0}, sc_pop[6] = {0, 0, 0, 0, 0, 0}, sc_cyc[6] = {0, 0, 0, 0, 0, 0};
   for (;;) {
+    // a finished traversal goes to SHADE; lanes reading from their newest ChaCha block top the ring up first
+    if (state == ST_SHADE && rng.low()) state = ST_FILL;
     // ---- wave scheduler: run the state with the most lanes in it (ties -> TRAV, SHADE, FILL, GEN)
     int n_trav = __popcll(__ballot(state == ST_TRAV));
     int n_shade = __popcll(__ballot(state == ST_SHADE));
@@ -199,28 +211,25 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           sc_exec[ST_TRAV]++, sc_pop[ST_TRAV] += (unsigned)np;
         }
         if (state == ST_TRAV) {
-          // one LDS round trip: the whole 64-B op, then branch-free bookkeeping
-          const DevOp &op = ops[pc];
+          // one LDS round trip: the whole 64-B linked op {box, w_hit, w_miss}; every op stepped here is a box op,
+          // the successor words already carry the state the lane enters there (rl_render.hip link_ops)
+          const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
           double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
-          uint32_t code = op.code, skip = op.skip;
-          uint32_t kind = code & 0xFFu;
-          bool is_box = (kind == OP_BOX) | (kind == OP_BOX_SPH);
+          uint32_t w_hit = op.code, w_miss = op.skip;
           bool certain;
-          bool hitb = aabb_fast(bx, ra, closest, certain);
-          if (is_box && !(certain && ra.fast_ok && (code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, closest);  // rare: exact divisions
-          if (STATS) c_nodes += is_box ? 1u : 0u;
-          bool to_leaf = (kind == OP_SPHERE) | ((kind == OP_BOX_SPH) & hitb);  // pc stays: LEAF re-reads a, b
-          uint32_t npc = (is_box & !hitb) ? skip : ((kind == OP_BOX) ? pc + 1u : pc);
-          uint32_t nstate = (kind == OP_END) ? (rng.low() ? ST_FILL : ST_SHADE) : (to_leaf ? ST_LEAF : ST_TRAV);
-          pc = npc;
-          state = nstate;
+          bool hitb = aabb_fast(bx, ra, closest, certain);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+          if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
+          if (STATS) c_nodes++;
+          uint32_t w = hitb ? w_hit : w_miss;
+          pc = w & 0x1FFFFFFFu;
+          state = w >> 29;
         }
         if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
       }
     } else if (pick == ST_LEAF) {
       if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
-        const DevOp &op = ops[pc];
-        uint32_t a = op.a, b = op.b;
+        const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
+        uint32_t a = op.a, b = op.b, w = op.skip;
         Hit h{closest, hit_prim};
         if (STATS) c_sph++;
         if (sphere_hit(spheres[a & ~SPH_MOVING], a, o, d, time, 1e-10, h)) c_flag++;
@@ -229,8 +238,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           if (sphere_hit(spheres[b & ~SPH_MOVING], b, o, d, time, 1e-10, h)) c_flag++;
         }
         closest = h.t, hit_prim = h.prim;
-        pc = op.skip;
-        state = ST_TRAV;
+        pc = w & 0x1FFFFFFFu;
+        state = w >> 29;
       }
     } else if (pick == ST_FILL) {
       if (state == ST_FILL) {
@@ -306,8 +315,9 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             c_rays++;
             pix_rays++;
             ra = ray_aux(o, d);
-            pc = 0, closest = INF, hit_prim = NONE;
-            state = ST_TRAV;
+            if (!ra.fast_ok) ra.slack = INF;
+            pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
+            state = entry0 >> 29;
           }
         }
       }
@@ -386,8 +396,9 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           o = p;
           d = nd;
           ra = ray_aux(o, d);
-          pc = 0, closest = INF, hit_prim = NONE;
-          state = ST_TRAV;
+          if (!ra.fast_ok) ra.slack = INF;
+          pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
+          state = entry0 >> 29;
         }
       }
     }
