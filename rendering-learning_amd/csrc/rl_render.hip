@@ -19,6 +19,7 @@
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
 #include "rl_rtiow_wave_general.h"
+#include "rl_rtiow_pool.h"
 #include "rl_rtiow_wavefront.h"
 
 using namespace rl;
@@ -140,7 +141,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -389,10 +390,13 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.work_counter = (uint32_t *)scene->d_scratch;
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   P.out = (double *)d_out;
-  P.tune[0] = 16, P.tune[1] = 6;
-  if (const char *t = std::getenv("RL_TUNE")) {  // "iters,floor16" (A/B only)
-    unsigned a = 16, b = 12;
-    if (std::sscanf(t, "%u,%u", &a, &b) == 2) P.tune[0] = a, P.tune[1] = b;
+  P.tune[0] = 16, P.tune[1] = 6, P.tune[2] = 24, P.tune[3] = 40;
+  if (const char *t = std::getenv("RL_TUNE")) {  // "iters,floor16[,refill_batch,refill_fill]" (A/B only)
+    unsigned a = 16, b = 12, c = 24, d = 40;
+    int nf = std::sscanf(t, "%u,%u,%u,%u", &a, &b, &c, &d);
+    if (nf >= 2) P.tune[0] = a, P.tune[1] = b;
+    if (nf >= 3) P.tune[2] = c;
+    if (nf >= 4) P.tune[3] = d;
   }
 
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
@@ -420,6 +424,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
+  if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS
   if (variant == 0 && !general) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
@@ -441,6 +446,12 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       constexpr int NT = 768;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
+    } else if (variant == 5) {
+      constexpr int NT = 512;
+      rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
+    } else if (variant == 6) {
+      constexpr int NT = 256;
+      rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
     } else if (variant == 1) {
       constexpr int NT = 1024;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
@@ -462,7 +473,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
-  bool lpt = lpt_enabled && (variant >= 256 || variant == 4) && cam->samples_per_pixel >= 64;
+  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 5 || variant == 6) && cam->samples_per_pixel >= 64;
   if (variant == 3) P.sample_begin = 0, P.sample_end = cam->samples_per_pixel;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;

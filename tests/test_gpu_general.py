@@ -92,9 +92,17 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
         c = cam.render(world).data
         rl.api.set_rtiow_variant(3)  # experimental wavefront form: rays in HBM, TRAV / SHADE / GEN kernels per pass
         d = cam.render(world).data
+        rl.api.set_rtiow_variant(5)  # pooled form: rays handed between waves through LDS
+        st = {}
+        e = cam.render(world, stats=st).data
+        rl.api.set_rtiow_variant(768)
+        st0 = {}
+        cam.render(world, stats=st0)
     finally:
         rl.api.set_rtiow_variant(0)
-    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
+    for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
+        assert st[k] == st0[k], k
 
 
 def test_stress_scene_cfg5_reduced(rl, oracle, golden):

@@ -11,10 +11,10 @@ cam.render(w, stats=st)
 out = (C.c_uint64 * 32)()
 L = rl.api.render_lib(); L.rl_debug_sched.argtypes = [C.c_void_p, C.c_void_p]
 L.rl_debug_sched(w.device(), out)
-names = {0: "GEN", 1: "TRAV", 2: "SHADE", 3: "FILL", 5: "LEAF"}
+names = {0: "GEN", 1: "TRAV", 2: "SHADE", 3: "FILL", 5: "LEAF", 6: "REFILL", 7: "IDLE"}
 print("rays", st["rays"], "kernel_ms", st["kernel_ms"], "Mrays/s", st["rays"] / st["kernel_ms"] / 1e3)
 tot = sum(out[3 * k + 2] for k in names)
 for k, nm in names.items():
     ex, pop, cyc = out[3 * k], out[3 * k + 1], out[3 * k + 2]
-    if ex: print(f"{nm:6s} execs {ex:12d}  lanes served {pop:14d}  avg pop {pop/ex:6.2f}  lane-visits/ray {pop/st['rays']:.3f}  "
+    if ex or cyc: ex = max(ex, 1); print(f"{nm:6s} execs {ex:12d}  lanes served {pop:14d}  avg pop {pop/ex:6.2f}  lane-visits/ray {pop/st['rays']:.3f}  "
                  f"cycles/exec {cyc/ex:8.1f}  time share {100*cyc/tot:5.1f}%")
