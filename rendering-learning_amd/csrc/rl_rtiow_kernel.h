@@ -37,6 +37,7 @@ struct RtiowParams {
   uint32_t *pos_state;                         // per-pixel ChaCha word position (saved at pixel end when non-null)
   const uint32_t *tile_order;                  // slot>>6 -> tile (LPT order) or null
   uint32_t *tile_cost;                         // per-tile ray count accumulated at pixel end, or null
+  double k8u;                 // 8 * 2^-53, passed as a kernel argument so it lives in SGPRs (one v_fma instead of v_mov + v_fmac with a literal)
   uint32_t tune[4];           // wave kernel: [0] max TRAV steps per scheduling round, [1] leave-TRAV population floor in 1/16ths
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
 };

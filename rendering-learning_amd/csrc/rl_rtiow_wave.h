@@ -112,15 +112,18 @@ __device__ __forceinline__ RayAux ray_aux(D3 o, D3 d) {
 
 // Filtered AABB::hit. tmin_ is the kernel constant 1e-10 (> 0), tmax_ the closest hit so far.
 // `certain` = false: the caller must evaluate the reference's divisions (aabb_hit).
-__device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, double tmax_, bool &certain) {
+__device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, double tmax_, bool &certain, double k8u = 8.8817841970012523e-16) {
   const double tmin_ = 1e-10;
   double t0x = fma(b[0], ra.inv.x, -ra.oi.x), t1x = fma(b[1], ra.inv.x, -ra.oi.x);
   double t0y = fma(b[2], ra.inv.y, -ra.oi.y), t1y = fma(b[3], ra.inv.y, -ra.oi.y);
   double t0z = fma(b[4], ra.inv.z, -ra.oi.z), t1z = fma(b[5], ra.inv.z, -ra.oi.z);
   double tmin = fmax(fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z)), tmin_);
-  double tmax = fmin(fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z)), tmax_);
+  double tmax3 = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z)), tmax;
+  // = fmin(tmax3, tmax_): v_min_f64 is IEEE minNum (quiets a signalling NaN itself); written as asm because the
+  // compiler otherwise spends a v_max_f64 x,x canonicalisation on the loop-carried tmax_ in every step
+  asm("v_min_f64 %0, %1, %2" : "=v"(tmax) : "v"(tmax3), "v"(tmax_));
   double diff = tmax - tmin;
-  double thresh = fma(tmin + fabs(tmax), 8.8817841970012523e-16, ra.slack);  // 8u(|tmin|+|tmax|) + slack
+  double thresh = fma(tmin + fabs(tmax), k8u, ra.slack);  // 8u(|tmin|+|tmax|) + slack
   certain = fabs(diff) > thresh;                                            // false also for NaN / inf arithmetic
   return diff > 0.0;
 }
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
           uint32_t w_hit = op.code, w_miss = op.skip;
           bool certain;
-          bool hitb = aabb_fast(bx, ra, closest, certain);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+          bool hitb = aabb_fast(bx, ra, closest, certain, P.k8u);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
           if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
           if (STATS) c_nodes++;
           uint32_t w = hitb ? w_hit : w_miss;
@@ -340,25 +343,32 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           D3 normal = front ? outward : -outward;
           const DevMaterial &m = P.materials[P.sphere_material[si]];
           uint32_t kind = m.kind;
-          if (kind == RL_MAT_LAMBERTIAN) {
-            D3 dir = normal + rng.unit_sphere();
+          // shared sub-expressions, evaluated once per block instead of once per material branch (same values, same
+          // RNG order: the unit-sphere draw is the first draw of both Lambertian and Metal scatter)
+          const bool is_lamb = kind == RL_MAT_LAMBERTIAN, is_metal = kind == RL_MAT_METAL, is_diel = kind == RL_MAT_DIELECTRIC;
+          D3 us = d3(0.0, 0.0, 0.0);
+          if (is_lamb | is_metal) us = rng.unit_sphere();
+          D3 reflected = d - normal * (2.0 * dot(d, normal));  // material.rs reflect(): used by Metal
+          D3 vin = is_metal ? reflected : d;
+          D3 vn = vin;
+          double m2 = len2(vin);
+          if (is_metal | is_diel) vn = div_s(vin, sqrt(m2));  // normalize(): vec3.rs:56
+          if (is_lamb) {
+            D3 dir = normal + us;
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;
             thr = thr * texture_value(P, m.texture, 0.0, 0.0, p);
-          } else if (kind == RL_MAT_METAL) {
-            D3 reflected = d - normal * (2.0 * dot(d, normal));
-            nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
+          } else if (is_metal) {
+            nd = vn + us * m.fuzz;
             if (!(dot(nd, normal) > 0.0)) path_done = true;  // absorbed
             else thr = thr * ld3(m.albedo);
-          } else if (kind == RL_MAT_DIELECTRIC) {
+          } else if (is_diel) {
             double ri = front ? 1.0 / m.ior : m.ior;
-            double m2 = len2(d);
-            D3 ud;
+            D3 ud = vn;
             if (approx_eq_eps(m2, 0.0, 1e-16)) {
               c_flag++;
               ud = d;
-            } else
-              ud = normalize(d);
+            }
             double cos_theta = fmin(dot(-ud, normal), 1.0);
             double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
             bool reflect = ri * sin_theta > 1.0;
