@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 2
+#define RL_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ errors */
 #define RL_OK 0
@@ -142,14 +142,20 @@ typedef struct rl_material {
   double ior;        /* Dielectric.refraction_index */
 } rl_material;
 
-enum { RL_TEX_SOLID = 0, RL_TEX_CHECKER = 1, RL_TEX_IMAGE = 2 };
-typedef struct rl_texture { /* texture.rs:15,25,58 */
+enum { RL_TEX_SOLID = 0, RL_TEX_CHECKER = 1, RL_TEX_IMAGE = 2, RL_TEX_NOISE = 3 };
+typedef struct rl_texture { /* texture.rs:15,25,58,84 */
   uint32_t kind;
   uint32_t even, odd; /* Checker: texture ids */
-  uint32_t image;     /* Image: image id */
+  uint32_t image;     /* Image: image id;  Noise: perlin id */
   double color[3];    /* SolidColor.albedo */
-  double inv_scale;   /* Checker.inv_scale */
+  double inv_scale;   /* Checker.inv_scale;  Noise.scale */
 } rl_texture;
+
+/* perlin.rs:9-14: the tables Perlin::new drew from the caller's Rng (the device only evaluates noise()/turb()) */
+typedef struct rl_perlin {
+  double randvec[256][3];
+  uint32_t perm_x[256], perm_y[256], perm_z[256]; /* each a permutation of 0..255 */
+} rl_perlin;
 
 typedef struct rl_image { /* texture.rs:58 Image{Rgb32FImage}: linear RGB f32, row-major, top row first */
   uint32_t width, height;
@@ -168,6 +174,7 @@ typedef struct rl_rtiow_scene_desc {
   const rl_texture *textures;     uint32_t n_textures;
   const rl_image *images;         uint32_t n_images;
   rl_href root;
+  const rl_perlin *perlins;       uint32_t n_perlins; /* ABI v3 */
 } rl_rtiow_scene_desc;
 
 /* The DERIVED camera: outputs of Camera::new (camera.rs:72-118). The host keeps Camera::new

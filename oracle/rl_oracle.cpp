@@ -203,6 +203,14 @@ inline void face_normal(const Ray &r, V3 outward, V3 &normal, bool &front) {
   else normal = -outward, front = false;
 }
 
+void sphere_uv(V3 p, double &u, double &v) {  // sphere.rs:91-99 get_sphere_uv (host libm acos / atan2: consumed by Image textures only, colour-only)
+  const double PI = 3.14159265358979323846;
+  double theta = std::acos(-p.y);
+  double phi = std::atan2(-p.z, p.x) + PI;
+  u = phi / (2.0 * PI);
+  v = theta / PI;
+}
+
 bool hit_sphere(RtiowCtx &cx, const rl_sphere &s, const Ray &r, double tmin, double tmax, HitRecord &rec) {  // sphere.rs:32-75
   cx.c.sphere_tests++;
   V3 c0 = v3(s.center0);
@@ -227,7 +235,7 @@ bool hit_sphere(RtiowCtx &cx, const rl_sphere &s, const Ray &r, double tmin, dou
   if (!(l2 == 1.0 || std::fabs(l2 - 1.0) <= 1e-5)) cx.c.flagged++;
   face_normal(r, outward, rec.normal, rec.front);
   rec.p = p, rec.t = t, rec.mat = s.material;
-  rec.u = 0.0, rec.v = 0.0;  // get_sphere_uv (sphere.rs:91-99) is only consumed by Image textures: out of scope for spheres
+  sphere_uv(outward, rec.u, rec.v);  // sphere.rs:70
   return true;
 }
 
@@ -321,6 +329,47 @@ bool hit_href(RtiowCtx &cx, rl_href h, const Ray &r, double tmin, double tmax, H
   return false;
 }
 
+int32_t f64_as_i32(double x) {  // Rust `as i32`: saturating, NaN -> 0
+  if (std::isnan(x)) return 0;
+  if (x >= 2147483647.0) return INT32_MAX;
+  if (x <= -2147483648.0) return INT32_MIN;
+  return (int32_t)x;
+}
+
+double perlin_noise(const rl_perlin &pn, V3 p) {  // perlin.rs:39-66 + perlin_interp :101-125
+  double u = p.x - std::floor(p.x), v = p.y - std::floor(p.y), w = p.z - std::floor(p.z);
+  uint32_t i = (uint32_t)f64_as_i32(std::floor(p.x)), j = (uint32_t)f64_as_i32(std::floor(p.y)), k = (uint32_t)f64_as_i32(std::floor(p.z));
+  const double *c[2][2][2];
+  for (uint32_t di = 0; di < 2; di++)
+    for (uint32_t dj = 0; dj < 2; dj++)
+      for (uint32_t dk = 0; dk < 2; dk++)
+        c[di][dj][dk] = pn.randvec[(pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u]) & 255u];
+  double uu = u * u * (3.0 - 2.0 * u);
+  double vv = v * v * (3.0 - 2.0 * v);
+  double ww = w * w * (3.0 - 2.0 * w);
+  double accum = 0.0;
+  for (int a = 0; a < 2; a++)
+    for (int b = 0; b < 2; b++)
+      for (int e = 0; e < 2; e++) {
+        double i_f = (double)a, j_f = (double)b, k_f = (double)e;
+        V3 weight_v{u - i_f, v - j_f, w - k_f};
+        accum += (i_f * uu + (1.0 - i_f) * (1.0 - uu)) * (j_f * vv + (1.0 - j_f) * (1.0 - vv)) * (k_f * ww + (1.0 - k_f) * (1.0 - ww)) *
+                 dot(v3(c[a][b][e]), weight_v);
+      }
+  return accum;
+}
+
+double perlin_turb(const rl_perlin &pn, V3 p, uint32_t depth) {  // perlin.rs:68-80
+  double accum = 0.0, weight = 1.0;
+  V3 temp_p = p;
+  for (uint32_t it = 0; it < depth; it++) {
+    accum += weight * perlin_noise(pn, temp_p);
+    weight *= 0.5;
+    temp_p = temp_p * 2.0;
+  }
+  return std::fabs(accum);
+}
+
 V3 texture_value(const rl_rtiow_scene_desc &d, uint32_t tex, double u, double v, V3 p) {  // texture.rs
   const rl_texture &t = d.textures[tex];
   switch (t.kind) {
@@ -339,6 +388,10 @@ V3 texture_value(const rl_rtiow_scene_desc &d, uint32_t tex, double u, double v,
       int64_t sum = (int64_t)((uint64_t)xi + (uint64_t)yi + (uint64_t)zi);
       bool is_even = (sum % 2) == 0;
       return texture_value(d, is_even ? t.even : t.odd, u, v, p);
+    }
+    case RL_TEX_NOISE: {  // texture.rs:84-94
+      double sv = 1.0 + std::sin(t.inv_scale * p.z + 10.0 * perlin_turb(d.perlins[t.image], p, 7));
+      return V3{0.5 * sv, 0.5 * sv, 0.5 * sv};
     }
     case RL_TEX_IMAGE: {  // texture.rs:62-82
       const rl_image &im = d.images[t.image];
@@ -1175,6 +1228,9 @@ int rlo_rtiow_hit(const rl_rtiow_scene_desc *desc, const double o[3], const doub
   std::memcpy(out, v, sizeof v);
   return 1;
 }
+void rlo_sphere_uv(const double p[3], double out[2]) { sphere_uv(v3(p), out[0], out[1]); }
+double rlo_perlin_noise(const rl_perlin *pn, const double p[3]) { return perlin_noise(*pn, v3(p)); }
+double rlo_perlin_turb(const rl_perlin *pn, const double p[3], uint32_t depth) { return perlin_turb(*pn, v3(p), depth); }
 int rlo_aabb_hit(const double bbox[6], const double o[3], const double d[3], double tmin, double tmax) {
   Ray r{v3(o), v3(d), 0.0};
   return aabb_hit(bbox, r, tmin, tmax) ? 1 : 0;

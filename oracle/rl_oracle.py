@@ -34,6 +34,11 @@ def lib():
         L.rlo_rtiow_pixel.argtypes = [vp, vp, u64, u32, u32, vp, C.POINTER(u64)]
         L.rlo_rtiow_hit.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp]
         L.rlo_aabb_hit.argtypes = [vp, vp, vp, dbl, dbl]
+        L.rlo_sphere_uv.argtypes = [vp, vp]
+        L.rlo_perlin_noise.argtypes = [vp, vp]
+        L.rlo_perlin_noise.restype = dbl
+        L.rlo_perlin_turb.argtypes = [vp, vp, u32]
+        L.rlo_perlin_turb.restype = dbl
         L.rlo_rtc_intersect.argtypes = [vp, vp, vp, vp, vp, vp, u32]
         L.rlo_rtc_color_at.argtypes = [vp, vp, vp, vp]
         L.rlo_rtc_lighting.argtypes = [vp, vp, vp, vp, vp, vp, dbl, vp]
@@ -113,6 +118,24 @@ def rtiow_hit(desc, o, d, time=0.0, tmin=0.0, tmax=float("inf")):
     if not lib().rlo_rtiow_hit(desc, o.ctypes.data, d.ctypes.data, time, tmin, tmax, out.ctypes.data):
         return None
     return dict(t=out[0], p=out[1:4].copy(), normal=out[4:7].copy(), front=bool(out[7]), u=out[8], v=out[9], mat=int(out[10]))
+
+
+def sphere_uv(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.zeros(2)
+    lib().rlo_sphere_uv(p.ctypes.data, out.ctypes.data)
+    return float(out[0]), float(out[1])
+
+
+def perlin_noise(perlin, p):
+    """perlin: a 1-element array of api.PERLIN dtype (rl_perlin)."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    return float(lib().rlo_perlin_noise(perlin.ctypes.data, p.ctypes.data))
+
+
+def perlin_turb(perlin, p, depth=7):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    return float(lib().rlo_perlin_turb(perlin.ctypes.data, p.ctypes.data, depth))
 
 
 def aabb_hit(bbox, o, d, tmin, tmax):

@@ -69,6 +69,7 @@ HREF = np.dtype([("kind", "<u4"), ("index", "<u4")])
 SPHERE = np.dtype([("center0", "<f8", 3), ("center1", "<f8", 3), ("radius", "<f8"), ("moving", "<u4"), ("material", "<u4")])
 MATERIAL = np.dtype([("kind", "<u4"), ("texture", "<u4"), ("albedo", "<f8", 3), ("fuzz", "<f8"), ("ior", "<f8")])
 TEXTURE = np.dtype([("kind", "<u4"), ("even", "<u4"), ("odd", "<u4"), ("image", "<u4"), ("color", "<f8", 3), ("inv_scale", "<f8")])
+PERLIN = np.dtype([("randvec", "<f8", (256, 3)), ("perm_x", "<u4", 256), ("perm_y", "<u4", 256), ("perm_z", "<u4", 256)])
 RTC_TRIANGLE = np.dtype([("p1", "<f8", 3), ("e1", "<f8", 3), ("e2", "<f8", 3), ("smooth", "<u4"), ("material", "<u4"),
                          ("n1", "<f8", 3), ("n2", "<f8", 3), ("n3", "<f8", 3)])
 RTC_GROUP = np.dtype([("first", "<u4"), ("count", "<u4")])
@@ -83,7 +84,7 @@ RTC_PATTERN = np.dtype([("kind", "<u4"), ("reserved", "<u4"), ("a", "<f8", 3), (
 RTC_LIGHT = np.dtype([("position", "<f8", 3), ("intensity", "<f8", 3)])
 
 MAT_FLAT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3, 4
-TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
+TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_NOISE = 0, 1, 2, 3
 O_TRIANGLE, O_GROUP, O_BOUNDED, O_TRANSFORMED, O_SPHERE, O_PLANE, O_CUBE, O_CYLINDER, O_CONE, O_CSG = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = 0, 1, 2
 PAT_STRIPE, PAT_RING, PAT_GRADIENT, PAT_CHECKER3D = 1, 2, 3, 4
@@ -269,6 +270,26 @@ class World:
         return World(host_lib().rlh_rtiow_cow_scene(obj_text, len(obj_text), rgb8.ctypes.data, w, h))
 
     @staticmethod
+    def perlin_spheres():  # examples/perlin_spheres.rs
+        L = host_lib()
+        L.rlh_rtiow_perlin_scene.restype, L.rlh_rtiow_perlin_scene.argtypes = C.c_void_p, [C.c_int]
+        return World(L.rlh_rtiow_perlin_scene(0))
+
+    @staticmethod
+    def simple_light():  # examples/simple_light.rs
+        L = host_lib()
+        L.rlh_rtiow_perlin_scene.restype, L.rlh_rtiow_perlin_scene.argtypes = C.c_void_p, [C.c_int]
+        return World(L.rlh_rtiow_perlin_scene(1))
+
+    @staticmethod
+    def earth_scene(rgb8: np.ndarray):  # examples/earth.rs with the caller's image (sRGB8, [H, W, 3])
+        L = host_lib()
+        L.rlh_rtiow_earth_scene.restype, L.rlh_rtiow_earth_scene.argtypes = C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32]
+        rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        h, w = rgb8.shape[:2]
+        return World(L.rlh_rtiow_earth_scene(rgb8.ctypes.data, w, h))
+
+    @staticmethod
     def stress_scene(n_side=1000, subdiv=2, obj_text: bytes = None, rgb8: np.ndarray = None, seed=5):
         """BASELINE configs[4]: n_side^2 small spheres + ground + subdivided spot mesh (see host/scenes.hpp)."""
         L = host_lib()
@@ -320,6 +341,7 @@ class SceneBuilder:
         for n, a in (("rlh_builder_free", [C.c_void_p]), ("rlh_b_solid", [C.c_void_p, C.c_void_p]),
                      ("rlh_b_checker", [C.c_void_p, C.c_double, C.c_int, C.c_int]),
                      ("rlh_b_image", [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+                     ("rlh_b_noise", [C.c_void_p, C.c_double, C.c_uint64]),
                      ("rlh_b_material", [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_double, C.c_double]),
                      ("rlh_b_sphere", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int]),
                      ("rlh_b_planar", [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -353,6 +375,10 @@ class SceneBuilder:
     def image(self, rgb_f32):
         a = np.ascontiguousarray(rgb_f32, dtype=np.float32)
         return self._chk(self._L.rlh_b_image(self._b, a.ctypes.data, a.shape[1], a.shape[0]))
+
+    def noise(self, scale, seed):
+        """Noise{Perlin::new(&mut Xoshiro256PlusPlus::seed_from_u64(seed)), scale} (texture.rs:84)."""
+        return self._chk(self._L.rlh_b_noise(self._b, scale, seed))
 
     def lambertian(self, tex):
         return self._chk(self._L.rlh_b_material(self._b, MAT_LAMBERTIAN, tex, None, 0.0, 1.0))

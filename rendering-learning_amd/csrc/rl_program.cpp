@@ -33,7 +33,7 @@ struct RtiowCompiler {
       default: return fail("unknown hittable kind");
     }
   }
-  uint32_t sphere_payload(uint32_t idx) { return idx | (d.spheres[idx].moving ? SPH_MOVING : 0u); }
+  uint32_t sphere_payload(uint32_t idx) { return idx | (d.spheres[idx].moving ? SPH_MOVING : 0u) | (p.sphere_uv[idx] ? SPH_UV : 0u); }
 
   bool emit(rl_href h, uint32_t depth) {
     if (depth > MAX_NEST) return fail("scene graph too deep");
@@ -153,8 +153,22 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
   if (!need(d.spheres, d.n_spheres, "spheres") || !need(d.planars, d.n_planars, "planars") || !need(d.translates, d.n_translates, "translates") ||
       !need(d.transforms, d.n_transforms, "transforms") || !need(d.bvh_nodes, d.n_bvh_nodes, "bvh_nodes") || !need(d.lists, d.n_lists, "lists") ||
       !need(d.list_items, d.n_list_items, "list_items") || !need(d.materials, d.n_materials, "materials") ||
-      !need(d.textures, d.n_textures, "textures") || !need(d.images, d.n_images, "images"))
+      !need(d.textures, d.n_textures, "textures") || !need(d.images, d.n_images, "images") || !need(d.perlins, d.n_perlins, "perlins"))
     return RL_E_INVALID;
+  if (d.n_spheres > SPH_INDEX) {
+    err = "too many spheres";
+    return RL_E_INVALID;
+  }
+  for (uint32_t i = 0; i < d.n_perlins; i++) {  // perlin.rs:17-36: three permutations of 0..255
+    const rl_perlin &pn = d.perlins[i];
+    for (const uint32_t *perm : {pn.perm_x, pn.perm_y, pn.perm_z})
+      for (int k = 0; k < 256; k++)
+        if (perm[k] > 255u) {
+          err = "perlin permutation entry out of range";
+          return RL_E_INVALID;
+        }
+    p.perlins.push_back(pn);
+  }
 
   // textures / images / materials
   for (uint32_t i = 0; i < d.n_images; i++) {
@@ -181,6 +195,12 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
         err = "image index out of range";
         return RL_E_INVALID;
       }
+    } else if (t.kind == RL_TEX_NOISE) {
+      if (t.image >= d.n_perlins) {
+        err = "perlin index out of range";
+        return RL_E_INVALID;
+      }
+      p.has_noise = true;
     } else if (t.kind != RL_TEX_SOLID) {
       err = "unknown texture kind";
       return RL_E_INVALID;
@@ -221,12 +241,29 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
     }
     p.materials.push_back(DevMaterial{m.kind, m.texture, {m.albedo[0], m.albedo[1], m.albedo[2]}, m.fuzz, m.ior});
   }
+  // which materials sample an Image (their spheres must carry UVs)
+  std::vector<uint8_t> mat_uv(d.n_materials, 0);
+  for (uint32_t i = 0; i < d.n_materials; i++) {
+    const rl_material &m = d.materials[i];
+    if (m.kind != RL_MAT_LAMBERTIAN && m.kind != RL_MAT_DIFFUSE_LIGHT) continue;
+    std::vector<uint32_t> st{m.texture};
+    std::vector<uint8_t> seen(d.n_textures, 0);
+    while (!st.empty()) {
+      uint32_t t = st.back();
+      st.pop_back();
+      if (seen[t]) continue;
+      seen[t] = 1;
+      if (d.textures[t].kind == RL_TEX_IMAGE) mat_uv[i] = 1;
+      if (d.textures[t].kind == RL_TEX_CHECKER) st.push_back(d.textures[t].even), st.push_back(d.textures[t].odd);
+    }
+  }
   for (uint32_t i = 0; i < d.n_spheres; i++) {
     const rl_sphere &s = d.spheres[i];
     if (s.material >= d.n_materials) {
       err = "sphere material out of range";
       return RL_E_INVALID;
     }
+    p.sphere_uv.push_back(mat_uv[s.material]);
     DevSphere ds{};
     for (int k = 0; k < 3; k++) {
       ds.c0[k] = s.center0[k];

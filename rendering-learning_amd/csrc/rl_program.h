@@ -31,6 +31,8 @@ enum : uint32_t {
 static const uint32_t BOX_FINITE = 0x100u;  // flag OR-ed into a box op's code: all six bounds finite, |b| <= 1e100
 static const uint32_t NONE = 0xFFFFFFFFu;
 static const uint32_t SPH_MOVING = 0x80000000u;  // flag bit in a sphere index payload
+static const uint32_t SPH_UV = 0x40000000u;      // flag bit: the sphere's texture tree holds an Image, so Sphere::hit must produce get_sphere_uv (sphere.rs:70,91-99)
+static const uint32_t SPH_INDEX = 0x3FFFFFFFu;
 
 struct alignas(16) DevOp {  // 64 B
   double box[6];            // x.min,x.max,y.min,y.max,z.min,z.max
@@ -81,7 +83,9 @@ struct RtiowProgram {
   std::vector<DevTexture> textures;
   std::vector<DevImage> images;
   std::vector<float> image_pool;
-  bool has_planars = false, has_instances = false, has_images = false;
+  std::vector<rl_perlin> perlins;
+  std::vector<uint8_t> sphere_uv;  // per sphere: texture tree reaches an Image
+  bool has_planars = false, has_instances = false, has_images = false, has_noise = false;
   uint32_t max_instance_depth = 0;
 };
 

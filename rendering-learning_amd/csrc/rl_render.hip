@@ -91,6 +91,7 @@ struct rl_scene {
   DevTexture *d_textures = nullptr;
   DevImage *d_images = nullptr;
   float *d_image_pool = nullptr;
+  rl_perlin *d_perlins = nullptr;
   // RTC
   RtcProgram rc;
   DevTri *d_tris = nullptr;
@@ -169,7 +170,7 @@ int rl_device_info(char *name, int cap) {
 void rl_scene_destroy(rl_scene *s) {
   if (!s) return;
   hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
-  hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool);
+  hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
   hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns);
@@ -230,32 +231,15 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
     delete s;
     return nullptr;
   }
-  // spheres do not carry UVs on the device (sphere.rs:91-99 is consumed only by Image textures)
-  for (size_t i = 0; i < s->rt.spheres.size(); i++) {
-    const DevMaterial &m = s->rt.materials[s->rt.sphere_material[i]];
-    if (m.kind != RL_MAT_LAMBERTIAN && m.kind != RL_MAT_DIFFUSE_LIGHT) continue;
-    std::vector<uint32_t> st{m.texture};
-    size_t visited = 0;
-    while (!st.empty() && visited++ < 100000) {
-      const DevTexture &t = s->rt.textures[st.back()];
-      st.pop_back();
-      if (t.kind == RL_TEX_IMAGE) {
-        set_err(RL_E_UNSUPPORTED, "Image texture on a sphere (needs sphere UVs) is not supported");
-        delete s;
-        return nullptr;
-      }
-      if (t.kind == RL_TEX_CHECKER) st.push_back(t.even), st.push_back(t.odd);
-    }
-  }
   int rc = RL_OK;
   if ((rc = upload(s->rt.ops, &s->d_ops)) || (rc = upload(s->rt.spheres, &s->d_spheres)) || (rc = upload(s->rt.sphere_material, &s->d_sphere_material)) ||
       (rc = upload(s->rt.planars, &s->d_planars)) || (rc = upload(s->rt.translates, &s->d_translates)) || (rc = upload(s->rt.transforms, &s->d_transforms)) ||
       (rc = upload(s->rt.materials, &s->d_materials)) || (rc = upload(s->rt.textures, &s->d_textures)) || (rc = upload(s->rt.images, &s->d_images)) ||
-      (rc = upload(s->rt.image_pool, &s->d_image_pool)) || (rc = scene_common(s))) {
+      (rc = upload(s->rt.image_pool, &s->d_image_pool)) || (rc = upload(s->rt.perlins, &s->d_perlins)) || (rc = scene_common(s))) {
     rl_scene_destroy(s);
     return nullptr;
   }
-  if (!(s->rt.has_planars || s->rt.has_instances || s->rt.has_images) && s->rt.ops.size() < (1u << 29)) {
+  if (!(s->rt.has_planars || s->rt.has_instances || s->rt.has_images || s->rt.has_noise) && s->rt.ops.size() < (1u << 29)) {
     std::vector<DevOp> lops;
     s->entry0 = link_ops(s->rt.ops, lops);
     if (upload(lops, &s->d_lops) != RL_OK) {
@@ -376,7 +360,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   RtiowParams P{};
   P.ops = scene->d_ops, P.spheres = scene->d_spheres, P.sphere_material = scene->d_sphere_material;
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
-  P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool;
+  P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins;
   P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
   P.lops = scene->d_lops, P.entry0 = scene->entry0;
   P.cam = *cam;
@@ -422,7 +406,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
-  bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images;
+  bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images || scene->rt.has_noise;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
   if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS

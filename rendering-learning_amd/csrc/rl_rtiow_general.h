@@ -62,6 +62,7 @@ __device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payl
   D3 outward = (p - center) * s.inv_r;
   double l2 = len2(outward);
   r.t = t, r.p = p, r.u = 0.0, r.v = 0.0, r.mat = mat, r.pc = pc, r.any = true;
+  if (payload & SPH_UV) sphere_uv(outward, r.u, r.v);  // only spheres whose texture tree samples an Image (sphere.rs:70)
   face_normal(d, outward, r.normal, r.front);
   return !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
 }
@@ -196,11 +197,11 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
             uint32_t a = op.a, b = op.b;
             if (code == OP_BOX_SPH) {
               if (STATS) c_sph++;
-              uint32_t ai = a & ~SPH_MOVING;
+              uint32_t ai = a & SPH_INDEX;
               if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
               if (b != NONE) {
                 if (STATS) c_sph++;
-                uint32_t bi = b & ~SPH_MOVING;
+                uint32_t bi = b & SPH_INDEX;
                 if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec)) c_flag++;
               }
             } else {
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           }
           if (code == OP_SPHERE) {
             if (STATS) c_sph++;
-            uint32_t a = op.a, ai = a & ~SPH_MOVING;
+            uint32_t a = op.a, ai = a & SPH_INDEX;
             if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
             pc++;
             continue;
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           D3 dir = normal + rc.unit_sphere(rng);
           bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
           nd = near_zero ? normal : dir;
-          thr = thr * texture_value(P, m.texture, rec.u, rec.v, p);
+          thr = thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
         } else if (kind == RL_MAT_METAL) {
           D3 reflected = wd - normal * (2.0 * dot(wd, normal));
           nd = normalize(reflected) + rc.unit_sphere(rng) * m.fuzz;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
             nd = perp + par;
           }
         } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-          color = color + thr * texture_value(P, m.texture, rec.u, rec.v, p);
+          color = color + thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
           break;
         } else {
           break;

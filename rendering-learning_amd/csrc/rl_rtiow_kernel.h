@@ -23,6 +23,7 @@ struct RtiowParams {
   const DevTexture *textures;
   const DevImage *images;
   const float *image_pool;
+  const rl_perlin *perlins;
   uint32_t n_ops, n_spheres;
   const DevOp *lops;  // wave kernel: ops with {code, skip} replaced by linked successor words (state << 29 | op index), see link_ops
   uint32_t entry0;    // linked word of op 0: where (and in which state) a new ray starts
@@ -175,7 +176,60 @@ __device__ __forceinline__ bool sphere_hit(const DevSphere &s, uint32_t payload,
   return !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
 }
 
-// texture.rs: value(u, v, p)
+// Rust `f64 as i32`: saturating, NaN -> 0
+__device__ __forceinline__ int f64_as_i32(double x) {
+  return x != x ? 0 : (x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (int)(-2147483647 - 1) : (int)x));
+}
+
+// perlin.rs:39-66,101-125: Perlin::noise = trilinear Hermite blend of dot(randvec[hash], offset) over the cell's 8 corners
+__device__ __forceinline__ double perlin_noise(const rl_perlin &pn, D3 p) {
+  double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+  double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  uint32_t i = (uint32_t)f64_as_i32(fx), j = (uint32_t)f64_as_i32(fy), k = (uint32_t)f64_as_i32(fz);
+  double uu = u * u * (3.0 - 2.0 * u);
+  double vv = v * v * (3.0 - 2.0 * v);
+  double ww = w * w * (3.0 - 2.0 * w);
+  double accum = 0.0;
+#pragma unroll
+  for (uint32_t di = 0; di < 2; di++)
+#pragma unroll
+    for (uint32_t dj = 0; dj < 2; dj++)
+#pragma unroll
+      for (uint32_t dk = 0; dk < 2; dk++) {
+        uint32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
+        D3 c = ld3(pn.randvec[h & 255u]);
+        double i_f = (double)di, j_f = (double)dj, k_f = (double)dk;
+        D3 weight_v = d3(u - i_f, v - j_f, w - k_f);
+        accum += (i_f * uu + (1.0 - i_f) * (1.0 - uu)) * (j_f * vv + (1.0 - j_f) * (1.0 - vv)) * (k_f * ww + (1.0 - k_f) * (1.0 - ww)) * dot(c, weight_v);
+      }
+  return accum;
+}
+
+// perlin.rs:68-80
+__device__ __forceinline__ double perlin_turb(const rl_perlin &pn, D3 p, uint32_t depth) {
+  double accum = 0.0, weight = 1.0;
+  D3 temp_p = p;
+#pragma unroll 1
+  for (uint32_t it = 0; it < depth; it++) {
+    accum += weight * perlin_noise(pn, temp_p);
+    weight *= 0.5;
+    temp_p = temp_p * 2.0;
+  }
+  return fabs(accum);
+}
+
+// sphere.rs:91-99 get_sphere_uv (acos / atan2 are the device libm's: colour-only)
+__device__ __forceinline__ void sphere_uv(D3 p, double &u, double &v) {
+  const double PI = 3.14159265358979323846;
+  double theta = acos(-p.y);
+  double phi = atan2(-p.z, p.x) + PI;
+  u = phi / (2.0 * PI);
+  v = theta / PI;
+}
+
+// texture.rs: value(u, v, p).  FULL = false compiles the Noise and Image branches out (the sphere-only kernels never
+// see them: scenes with Noise / Image textures are routed to the all-primitives kernels by rl_rtiow_render_device).
+template <bool FULL = false>
 __device__ __forceinline__ D3 texture_value(const RtiowParams &P, uint32_t tex, double u, double v, D3 p) {
   for (int guard = 0; guard < 64; guard++) {
     const DevTexture &t = P.textures[tex];
@@ -188,6 +242,11 @@ __device__ __forceinline__ D3 texture_value(const RtiowParams &P, uint32_t tex, 
       long long sum = (long long)((unsigned long long)xi + (unsigned long long)yi + (unsigned long long)zi);
       tex = ((sum % 2) == 0) ? t.even : t.odd;
       continue;
+    }
+    if (!FULL) return D3{0.0, 0.0, 0.0};
+    if (t.kind == RL_TEX_NOISE) {  // texture.rs:84-94: Color(0.5,0.5,0.5) * (1 + sin(scale * p.z + 10 * turb(p, 7)))
+      double sv = 1.0 + sin(t.inv_scale * p.z + 10.0 * perlin_turb(P.perlins[t.image], p, 7u));
+      return D3{0.5 * sv, 0.5 * sv, 0.5 * sv};
     }
     // RL_TEX_IMAGE (texture.rs:62-82): nearest texel, f32 linear RGB
     const DevImage &im = P.images[t.image];
@@ -287,7 +346,7 @@ __global__ void __launch_bounds__(NT) rtiow_spheres_kernel(RtiowParams P) {
           if (code == OP_SPHERE) {
             if (STATS) cnt.spheres++;
             uint32_t a = op.a;
-            if (sphere_hit(spheres[a & ~SPH_MOVING], a, o, d, time, 1e-10, h)) cnt.flagged++;
+            if (sphere_hit(spheres[a & SPH_INDEX], a, o, d, time, 1e-10, h)) cnt.flagged++;
             pc++;
             continue;
           }
@@ -304,10 +363,10 @@ __global__ void __launch_bounds__(NT) rtiow_spheres_kernel(RtiowParams P) {
           }
           uint32_t a = op.a, b = op.b;
           if (STATS) cnt.spheres++;
-          if (sphere_hit(spheres[a & ~SPH_MOVING], a, o, d, time, 1e-10, h)) cnt.flagged++;
+          if (sphere_hit(spheres[a & SPH_INDEX], a, o, d, time, 1e-10, h)) cnt.flagged++;
           if (b != NONE) {
             if (STATS) cnt.spheres++;
-            if (sphere_hit(spheres[b & ~SPH_MOVING], b, o, d, time, 1e-10, h)) cnt.flagged++;
+            if (sphere_hit(spheres[b & SPH_INDEX], b, o, d, time, 1e-10, h)) cnt.flagged++;
           }
           pc = skip;
         }
@@ -316,7 +375,7 @@ __global__ void __launch_bounds__(NT) rtiow_spheres_kernel(RtiowParams P) {
           break;
         }
         // rebuild the HitRecord of the winning sphere (same arithmetic as at test time)
-        uint32_t si = h.prim & ~SPH_MOVING;
+        uint32_t si = h.prim & SPH_INDEX;
         const DevSphere &s = spheres[si];
         D3 c0 = ld3(s.c0);
         D3 center = (h.prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;

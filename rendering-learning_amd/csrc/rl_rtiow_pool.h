@@ -221,10 +221,10 @@ __global__ void __launch_bounds__(NT) rtiow_pool_kernel(RtiowParams P) {
         uint32_t a = op.a, b = op.b, w = op.skip;
         Hit h{closest, hit_prim};
         if (STATS) c_sph++;
-        if (sphere_hit(spheres[a & ~SPH_MOVING], a, so, sd, stime, 1e-10, h)) c_flag++;
+        if (sphere_hit(spheres[a & SPH_INDEX], a, so, sd, stime, 1e-10, h)) c_flag++;
         if (b != NONE) {
           if (STATS) c_sph++;
-          if (sphere_hit(spheres[b & ~SPH_MOVING], b, so, sd, stime, 1e-10, h)) c_flag++;
+          if (sphere_hit(spheres[b & SPH_INDEX], b, so, sd, stime, 1e-10, h)) c_flag++;
         }
         closest = h.t, hit_prim = h.prim;
         pc = w & 0x1FFFFFFFu;
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(NT) rtiow_pool_kernel(RtiowParams P) {
           sum = sum + thr * ld3(cam.background);
           path_done = true;
         } else {
-          uint32_t si = res_prim & ~SPH_MOVING;
+          uint32_t si = res_prim & SPH_INDEX;
           const DevSphere &s = spheres[si];
           D3 c0 = ld3(s.c0);
           D3 center = (res_prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;

@@ -91,11 +91,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
         uint32_t kind = op.code & 0xFFu;
         uint32_t a = op.a, b = op.b;
         if (kind == OP_BOX_SPH || kind == OP_SPHERE) {
-          uint32_t ai = a & ~SPH_MOVING;
+          uint32_t ai = a & SPH_INDEX;
           if (STATS) c_sph++;
           if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
           if (b != NONE) {
-            uint32_t bi = b & ~SPH_MOVING;
+            uint32_t bi = b & SPH_INDEX;
             if (STATS) c_sph++;
             if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec)) c_flag++;
           }
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
             D3 dir = normal + rng.unit_sphere();
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;
-            thr = thr * texture_value(P, m.texture, rec.u, rec.v, p);
+            thr = thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
           } else if (kind == RL_MAT_METAL) {
             D3 reflected = wd - normal * (2.0 * dot(wd, normal));
             nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
               nd = perp + par;
             }
           } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-            sum = sum + thr * texture_value(P, m.texture, rec.u, rec.v, p);
+            sum = sum + thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
             path_done = true;
           } else {
             path_done = true;

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NT) wf_shade(WfParams W) {
         uint32_t x, y;
         Rng rng;
         rng_load<NT>(ps, s_rng, tid, rng, pixel_stream(P, pix, ps.n, x, y));
-        uint32_t si = hr.prim & ~SPH_MOVING;
+        uint32_t si = hr.prim & SPH_INDEX;
         const DevSphere &s = P.spheres[si];
         D3 c0 = ld3(s.c0);
         D3 center = (hr.prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
@@ -429,10 +429,10 @@ __global__ void __launch_bounds__(NT) wf_trav(WfParams W) {
         uint32_t a = op.a, b = op.b;
         Hit h{closest, hit_prim};
         if (STATS) c_sph++;
-        if (sphere_hit(spheres[a & ~SPH_MOVING], a, o, d, time, 1e-10, h)) c_flag++;
+        if (sphere_hit(spheres[a & SPH_INDEX], a, o, d, time, 1e-10, h)) c_flag++;
         if (b != NONE) {
           if (STATS) c_sph++;
-          if (sphere_hit(spheres[b & ~SPH_MOVING], b, o, d, time, 1e-10, h)) c_flag++;
+          if (sphere_hit(spheres[b & SPH_INDEX], b, o, d, time, 1e-10, h)) c_flag++;
         }
         closest = h.t, hit_prim = h.prim;
         pc = op.skip;

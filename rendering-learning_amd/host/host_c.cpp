@@ -61,6 +61,24 @@ rlh_rtiow *rlh_rtiow_cow_scene(const char *obj_text, uint64_t obj_len, const uin
   }
 }
 
+// examples/perlin_spheres.rs (light = 0) / examples/simple_light.rs (light = 1)
+rlh_rtiow *rlh_rtiow_perlin_scene(int light) {
+  try {
+    return finish(scenes::perlin_scene(light != 0));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+// examples/earth.rs with the caller's sRGB8 image
+rlh_rtiow *rlh_rtiow_earth_scene(const uint8_t *rgb8, uint32_t w, uint32_t h) {
+  try {
+    return finish(scenes::earth_scene(rgb8, w, h));
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 // BASELINE configs[4] stress scene (scenes.hpp::stress_scene); obj_text may be NULL (spheres only)
 rlh_rtiow *rlh_rtiow_stress_scene(int n_side, int subdiv, const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h,
                                   uint64_t seed) {
@@ -155,6 +173,12 @@ int rlh_b_image(rlh_builder *b, const float *rgb, uint32_t w, uint32_t h) {
   img->width = w, img->height = h;
   img->rgb.assign(rgb, rgb + (size_t)w * h * 3);
   b->tex.push_back(rtiow::Image(img));
+  return (int)b->tex.size() - 1;
+}
+// Noise{Perlin::new(&mut Xoshiro256PlusPlus::seed_from_u64(seed)), scale} (texture.rs:84-87)
+int rlh_b_noise(rlh_builder *b, double scale, uint64_t seed) {
+  auto rng = scenes::Xoshiro256PlusPlus::seed_from_u64(seed);
+  b->tex.push_back(rtiow::Noise(rtiow::Perlin::create(rng), scale));
   return (int)b->tex.size() - 1;
 }
 int rlh_b_material(rlh_builder *b, uint32_t kind, int tex, const double *albedo, double fuzz, double ior) {

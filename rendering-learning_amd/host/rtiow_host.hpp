@@ -108,12 +108,64 @@ struct ImageData {
   uint32_t width = 0, height = 0;
   std::vector<float> rgb;  // linear
 };
+// perlin.rs:9-36 Perlin::new(rand): 256 random unit vectors, then three Fisher-Yates permutations of 0..255, all
+// drawn from the caller's Rng in that order.  R needs next_u64() (rand_core RngCore).  The draws restate
+// rand_distr 0.4.3 UnitSphere (Uniform::new(-1., 1.) pairs, Marsaglia) and rand 0.8.5 gen_range(0..i) for usize
+// (widening-multiply rejection, UniformInt::sample_single).  No reference test pins these tables: "unpinned".
+struct Perlin {
+  rl_perlin tab;
+  template <class R>
+  static double uniform_m1_1(R &rng) {
+    uint64_t bits = (rng.next_u64() >> 12) | 0x3FF0000000000000ull;
+    double v12;
+    std::memcpy(&v12, &bits, 8);
+    return (v12 - 1.0) * 2.0 + (-1.0);
+  }
+  template <class R>
+  static uint64_t gen_range_usize(R &rng, uint64_t low, uint64_t high) {  // low..high, high > low
+    uint64_t range = high - low;
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    for (;;) {
+      unsigned __int128 m = (unsigned __int128)rng.next_u64() * range;
+      uint64_t hi = (uint64_t)(m >> 64), lo = (uint64_t)m;
+      if (lo <= zone) return low + hi;
+    }
+  }
+  template <class R>
+  static void permute(uint32_t *p, R &rng) {  // perlin.rs:83-90
+    for (uint64_t i = 255; i >= 1; i--) {
+      uint64_t target = gen_range_usize(rng, 0, i);
+      std::swap(p[i], p[target]);
+    }
+  }
+  template <class R>
+  static std::shared_ptr<Perlin> create(R &rng) {
+    auto pn = std::make_shared<Perlin>();
+    for (int i = 0; i < 256; i++) {  // Vec3::random_unit_vector (vec3.rs:72-75)
+      for (;;) {
+        double x1 = uniform_m1_1(rng), x2 = uniform_m1_1(rng);
+        double sum = x1 * x1 + x2 * x2;
+        if (sum >= 1.0) continue;
+        double factor = 2.0 * std::sqrt(1.0 - sum);
+        pn->tab.randvec[i][0] = x1 * factor, pn->tab.randvec[i][1] = x2 * factor, pn->tab.randvec[i][2] = 1.0 - 2.0 * sum;
+        break;
+      }
+    }
+    for (uint32_t *perm : {pn->tab.perm_x, pn->tab.perm_y, pn->tab.perm_z}) {
+      for (uint32_t i = 0; i < 256; i++) perm[i] = i;
+      permute(perm, rng);
+    }
+    return pn;
+  }
+};
+
 struct Texture {
   uint32_t kind = RL_TEX_SOLID;
   Color color;
-  double inv_scale = 0.0;
+  double inv_scale = 0.0;  // Checker: 1/scale; Noise: scale
   std::shared_ptr<Texture> even, odd;
   std::shared_ptr<ImageData> image;
+  std::shared_ptr<Perlin> noise;
 };
 using TexturePtr = std::shared_ptr<Texture>;
 inline TexturePtr SolidColor(const Color &albedo) {
@@ -134,6 +186,13 @@ inline TexturePtr Image(std::shared_ptr<ImageData> img) {
   auto t = std::make_shared<Texture>();
   t->kind = RL_TEX_IMAGE;
   t->image = img;
+  return t;
+}
+inline TexturePtr Noise(std::shared_ptr<Perlin> noise, double scale) {  // texture.rs:84-87
+  auto t = std::make_shared<Texture>();
+  t->kind = RL_TEX_NOISE;
+  t->noise = noise;
+  t->inv_scale = scale;
   return t;
 }
 struct Material {
@@ -183,6 +242,8 @@ struct Flattened {
   std::vector<rl_texture> textures;
   std::vector<rl_image> images;
   std::vector<std::shared_ptr<ImageData>> image_keep;
+  std::vector<rl_perlin> perlins;
+  std::map<const Perlin *, uint32_t> perlin_ids;
   std::map<const Material *, uint32_t> mat_ids;
   std::map<const Texture *, uint32_t> tex_ids;
   std::map<const ImageData *, uint32_t> img_ids;
@@ -208,6 +269,13 @@ struct Flattened {
         ii = img_ids.emplace(t->image.get(), (uint32_t)images.size() - 1).first;
       }
       r.image = ii->second;
+    } else if (t->kind == RL_TEX_NOISE) {
+      auto pi = perlin_ids.find(t->noise.get());
+      if (pi == perlin_ids.end()) {
+        perlins.push_back(t->noise->tab);
+        pi = perlin_ids.emplace(t->noise.get(), (uint32_t)perlins.size() - 1).first;
+      }
+      r.image = pi->second;
     }
     textures.push_back(r);
     uint32_t id = (uint32_t)textures.size() - 1;
@@ -240,6 +308,7 @@ struct Flattened {
     d.materials = materials.data(), d.n_materials = (uint32_t)materials.size();
     d.textures = textures.data(), d.n_textures = (uint32_t)textures.size();
     d.images = images.data(), d.n_images = (uint32_t)images.size();
+    d.perlins = perlins.data(), d.n_perlins = (uint32_t)perlins.size();
     d.root = root;
     return d;
   }

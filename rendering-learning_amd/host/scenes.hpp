@@ -287,6 +287,58 @@ inline RtiowScene cow_scene(const std::string &obj_text, const uint8_t *rgb8, ui
   return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
 }
 
+// examples/perlin_spheres.rs (light = false) and examples/simple_light.rs (light = true): two spheres with one shared
+// Lambertian{Noise{Perlin::new(Xoshiro256PlusPlus::seed_from_u64(1)), scale 4}}, plus a quad and a sphere light.
+inline RtiowScene perlin_scene(bool light) {
+  using namespace rtiow;
+  auto rng = Xoshiro256PlusPlus::seed_from_u64(1);
+  auto material = Lambertian(Noise(Perlin::create(rng), 4.0));
+  std::vector<HittablePtr> world;
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, -1000.0, 0.0)), 1000.0, material));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 2.0, 0.0)), 2.0, material));
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0;
+  p.image_width = 400;
+  p.samples_per_pixel = 100;
+  p.max_depth = 50;
+  p.vfov = 20.0;
+  p.lookfrom = Point3(13.0, 2.0, 3.0);
+  p.lookat = Point3(0.0, 0.0, 0.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.0;
+  if (light) {
+    auto light_material = DiffuseLight(SolidColor(Color(4.0, 4.0, 4.0)));
+    world.push_back(std::make_shared<Quad>(Point3(3.0, 1.0, -2.0), Vec3(2.0, 0.0, 0.0), Vec3(0.0, 2.0, 0.0), light_material));
+    world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 7.0, 0.0)), 2.0, light_material));
+    p.background = Color(0.0, 0.0, 0.0);
+    p.lookfrom = Point3(26.0, 3.0, 6.0);
+    p.lookat = Point3(0.0, 2.0, 0.0);
+  }
+  return RtiowScene{std::make_shared<HittableList>(std::move(world)), p};
+}
+
+// examples/earth.rs: one sphere of radius 2 with Lambertian{Image}; the image is the caller's (sRGB8 -> linear f32 as the
+// example converts it; earthmap.jpg itself is not decoded here).
+inline RtiowScene earth_scene(const uint8_t *rgb8, uint32_t tw, uint32_t th) {
+  using namespace rtiow;
+  auto img = std::make_shared<ImageData>();
+  img->width = tw, img->height = th;
+  img->rgb.resize((size_t)tw * th * 3);
+  for (size_t i = 0; i < img->rgb.size(); i++) img->rgb[i] = (float)srgb::srgb_to_linear((double)((float)rgb8[i] / 255.0f));
+  HittablePtr globe = std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 0.0, 0.0)), 2.0, Lambertian(Image(img)));
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0;
+  p.image_width = 400;
+  p.samples_per_pixel = 100;
+  p.max_depth = 50;
+  p.vfov = 20.0;
+  p.lookfrom = Point3(0.0, 0.0, 12.0);
+  p.lookat = Point3(0.0, 0.0, 0.0);
+  p.vup = Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.0;
+  return RtiowScene{globe, p};
+}
+
 // BASELINE configs[4] ("1M random spheres + 100k-triangle OBJ"): NOT in the reference — defined by
 // SURVEY.md §8d item 5 and frozen here.  n_side = 1000, subdiv = 2 gives 1,000,000 small spheres + the
 // ground sphere + spot_triangulated.obj midpoint-subdivided twice (5856 * 16 = 93,696 triangles, UVs

@@ -22,13 +22,14 @@ def test_header_symbols_all_exported(rl):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in rl_render.h but not exported"
     assert sorted(rl.api.RENDER_SYMBOLS) == syms
-    assert lib.rl_abi_version() == 2
+    assert lib.rl_abi_version() == 3
 
 
 def test_struct_layouts_match_header(rl):
     # sizes the C compiler produces for the PODs (computed by hand from the header)
     api = rl.api
     assert api.SPHERE.itemsize == 64 and api.MATERIAL.itemsize == 48 and api.TEXTURE.itemsize == 48
+    assert api.PERLIN.itemsize == 256 * 24 + 3 * 256 * 4
     assert api.RTC_TRIANGLE.itemsize == 152 and api.RTC_MATERIAL.itemsize == 88 and api.RTC_LIGHT.itemsize == 48
     assert api.RTC_BOUNDED.itemsize == 56 and api.RTC_TRANSFORMED.itemsize == 264
     assert api.RTC_SHAPE.itemsize == 40 and api.RTC_CSG.itemsize == 24 and api.RTC_PATTERN.itemsize == 184

@@ -40,6 +40,48 @@ def test_cow_scene_cfg4_reduced(rl, oracle, golden):
     assert gs["planar_tests"] > 0 and gs["instance_enters"] > 0
 
 
+def test_perlin_spheres_and_simple_light_vs_oracle(rl, oracle):
+    """examples/perlin_spheres.rs and simple_light.rs: Noise{Perlin} textures (perlin.rs, texture.rs:84-94), a quad light and
+    a sphere light.  The Perlin tables come from the host mirror of Perlin::new (unpinned); noise()/turb() run on the device."""
+    for world in (rl.World.perlin_spheres(), rl.World.simple_light()):
+        p = world.params
+        p.image_width, p.samples_per_pixel, p.max_depth = 96, 6, 20
+        _parity(rl, oracle, world, p)
+
+
+def test_noise_texture_through_the_scene_builder(rl, oracle):
+    def scene(b):
+        n1 = b.lambertian(b.noise(4.0, 7))
+        n2 = b.diffuse_light(b.checker(0.5, b.noise(1.5, 8), b.solid((0.2, 0.9, 0.3))))
+        objs = [b.sphere((0, -1000, 0), 1000, n1), b.sphere((0, 2, 0), 2, n2), b.sphere((3, 1, 2), 1, b.dielectric(1.5)),
+                b.quad((-4, 0, -3), (3, 0, 0), (0, 3, 0), n1)]
+        return b.bvh(objs)
+    world = rl.World.build(scene)
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=96, samples_per_pixel=6, max_depth=12, vfov=30.0, lookfrom=(13, 3, 5), lookat=(0, 1, 0))
+    _parity(rl, oracle, world, p)
+
+
+def test_earth_scene_image_texture_on_a_sphere(rl, oracle, golden):
+    """examples/earth.rs: Lambertian{Image} on a sphere needs get_sphere_uv (sphere.rs:91-99).  earthmap.jpg is not decoded
+    here; the spot texture stands in for it (same code path)."""
+    tex = _spot_texture()
+    world = rl.World.earth_scene(tex)
+    p = world.params
+    p.image_width, p.samples_per_pixel, p.max_depth = 96, 6, 20
+    _parity(rl, oracle, world, p)
+    # and inside a rotated / translated instance next to a moving textured sphere (uv is taken in object space)
+    lin = (tex.astype(np.float32) / 255.0) ** 2.2
+
+    def scene(b):
+        m = b.lambertian(b.image(lin))
+        s1 = b.translate(b.rotate_y(b.sphere((0, 0, 0), 1.5, m), 30.0), (1.0, 0.5, 0.0))
+        s2 = b.sphere((-3, 0, 0), 1.0, m, center2=(-3, 0.5, 0))
+        return b.bvh([s1, s2, b.sphere((0, -101.5, 0), 100, b.lambertian(b.solid((0.5, 0.5, 0.5))))])
+    world = rl.World.build(scene)
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=96, samples_per_pixel=6, max_depth=10, vfov=30.0, lookfrom=(0, 2, 12), lookat=(0, 0, 0))
+    _parity(rl, oracle, world, p)
+
+
 def test_composed_scene_all_primitive_kinds(rl, oracle):
     def scene(b):
         red = b.lambertian(b.solid((0.8, 0.2, 0.2)))

@@ -5,6 +5,7 @@ and checked against the oracle's probes.  Together with the two golden images th
   Sphere::hit               RTIOW src/hittable/sphere.rs:118-179
   slice closest hit         RTIOW src/hittable/mod.rs:226-250
   AABB::hit                 RTIOW src/aabb.rs:182-205
+  get_sphere_uv             RTIOW src/hittable/sphere.rs:181-207
   Triangle::intersect       RTC  src/scene/object/triangle.rs:170-251
   lighting                  RTC  src/scene/material.rs:136-274
 """
@@ -83,6 +84,44 @@ def test_equal_t_later_hittable_wins(rl, oracle):
     ((5, 5, 5), (0, 0, 1), -INF, INF, False), ((0, 3, 3), (1, 0, 0), 2.0, 3.0, True), ((0, 3, 3), (1, 0, 0), 1.0, 1.9, False)])
 def test_aabb_hit_known_answers(oracle, o, d, tmin, tmax, expected):
     assert oracle.aabb_hit((2, 4, 2, 4, 2, 4), o, d, tmin, tmax) is expected
+
+
+@pytest.mark.parametrize("p,uv", [((1, 0, 0), (0.5, 0.5)), ((0, 1, 0), (0.5, 1.0)), ((0, 0, 1), (0.25, 0.5)),
+                                  ((-1, 0, 0), (0.0, 0.5)), ((0, -1, 0), (0.5, 0.0)), ((0, 0, -1), (0.75, 0.5))])
+def test_sphere_uv_known_answers(oracle, p, uv):  # sphere.rs:198-205 (epsilon 0.01 there)
+    u, v = oracle.sphere_uv(p)
+    assert abs(u - uv[0]) <= 0.01 and abs(v - uv[1]) <= 0.01
+
+
+def test_sphere_hit_record_carries_uv(rl, oracle):  # sphere.rs:70: uv of the outward normal at the hit point
+    world = rl.World.build(lambda b: b.sphere((0, 0, 0), 2.0, b.lambertian(b.solid((1, 1, 1)))))
+    h = oracle.rtiow_hit(world.desc, (0, 0, 12), (0, 0, -1), 0.0, 1e-10, INF)   # hits (0, 0, 2): the +z pole of get_sphere_uv
+    assert h is not None and abs(h["t"] - 10.0) < 1e-12 and abs(h["u"] - 0.25) < 1e-12 and abs(h["v"] - 0.5) < 1e-12
+
+
+def test_perlin_noise_properties(rl, oracle):
+    """perlin.rs has no unit tests; these are properties of its algorithm: the Hermite-blended gradient noise vanishes on
+    the integer lattice, is periodic with the 256-cell permutation tables, stays inside [-1, 1] ("Outputs a noise value ...
+    in the range [-1, 1]", perlin.rs:38) and turb() is the |sum of 7 halved octaves|."""
+    rng = np.random.default_rng(5)
+    pn = np.zeros(1, dtype=rl.api.PERLIN)
+    v = rng.normal(size=(256, 3))
+    pn["randvec"][0] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    for k in ("perm_x", "perm_y", "perm_z"):
+        pn[k][0] = rng.permutation(256)
+    for p in ((0, 0, 0), (3, -7, 11), (255, 256, -256)):
+        assert oracle.perlin_noise(pn, p) == 0.0
+    pts = rng.uniform(-40, 40, size=(200, 3))
+    vals = np.array([oracle.perlin_noise(pn, p) for p in pts])
+    assert np.abs(vals).max() <= 1.0 and np.abs(vals).max() > 0.2
+    for p in pts[:20]:
+        assert abs(oracle.perlin_noise(pn, p + np.array([256.0, -512.0, 768.0])) - oracle.perlin_noise(pn, p)) < 1e-9
+        acc, w, q = 0.0, 1.0, np.array(p)
+        for _ in range(7):
+            acc += w * oracle.perlin_noise(pn, q)
+            w *= 0.5
+            q = q * 2.0
+        assert oracle.perlin_turb(pn, p, 7) == abs(acc)
 
 
 # ----------------------------------------------------------------------------- RTC
