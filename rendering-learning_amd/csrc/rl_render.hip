@@ -20,6 +20,7 @@
 #include "rl_rtiow_wave.h"
 #include "rl_rtiow_wave_general.h"
 #include "rl_rtiow_pool.h"
+#include "rl_rtiow_wave2.h"
 #include "rl_rtiow_wavefront.h"
 
 using namespace rl;
@@ -142,7 +143,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -409,6 +410,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images || scene->rt.has_noise;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
+  if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
   if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS
   if (variant == 0 && !general) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
@@ -434,6 +436,10 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     } else if (variant == 5) {
       constexpr int NT = 512;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
+    } else if (variant == 7) {
+      constexpr int NT = 512;
+      size_t rb = (size_t)8 * 2 * NT * sizeof(unsigned long long);
+      rc = want_stats ? launch(rtiow_wave2_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_wave2_kernel<NT, true, false>, NT, rb, true);
     } else if (variant == 6) {
       constexpr int NT = 256;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
@@ -458,7 +464,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
-  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 5 || variant == 6) && cam->samples_per_pixel >= 64;
+  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
   if (variant == 3) P.sample_begin = 0, P.sample_end = cam->samples_per_pixel;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;

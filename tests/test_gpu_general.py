@@ -137,14 +137,17 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
         rl.api.set_rtiow_variant(5)  # pooled form: rays handed between waves through LDS
         st = {}
         e = cam.render(world, stats=st).data
+        rl.api.set_rtiow_variant(7)  # two pixel contexts per lane, one-block ChaCha rings, restartable draws
+        st2 = {}
+        f = cam.render(world, stats=st2).data
         rl.api.set_rtiow_variant(768)
         st0 = {}
         cam.render(world, stats=st0)
     finally:
         rl.api.set_rtiow_variant(0)
-    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e) and np.array_equal(a, f)
     for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
-        assert st[k] == st0[k], k
+        assert st[k] == st0[k] and st2[k] == st0[k], k
 
 
 def test_stress_scene_cfg5_reduced(rl, oracle, golden):
