@@ -143,7 +143,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -410,11 +410,15 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images || scene->rt.has_noise;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
+  if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
   if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS
-  if (variant == 0 && !general) {  // automatic: the most waves per SIMD that still keep the scene LDS-resident; else 4 waves/SIMD reading HBM/L2
+  if (variant == 0 && !general) {
+    // automatic: 4 waves per SIMD with the ChaCha rings and the linked ops in LDS (spheres through L2) when that fits;
+    // else 3 (or 2) waves per SIMD with the whole scene in LDS; else 4 waves per SIMD reading everything from HBM / L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
-    variant = fits(768) ? 768 : fits(512) ? 512 : 1024;
+    bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
+    variant = fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
   auto launch_variant = [&]() -> int {
     int rc;
@@ -422,8 +426,8 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   {                                                                                                                     \
     size_t rb = (size_t)16 * NT * sizeof(unsigned long long);                                                           \
     bool in_lds = rb + scene_bytes <= g_lds_max;                                                                        \
-    if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, true, false>, NT, rb, true); \
-    else rc = want_stats ? launch(rtiow_wave_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, false, false>, NT, rb, false);   \
+    if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, 1, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, 1, false>, NT, rb, true); \
+    else rc = want_stats ? launch(rtiow_wave_kernel<NT, 0, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 0, false>, NT, rb, false);   \
   }
     if (variant == 2) {
       constexpr int NT = 256;
@@ -449,6 +453,10 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       bool in_lds = rb + scene_bytes <= g_lds_max;
       if (in_lds) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_spheres_kernel<NT, true, false>, NT, rb, true);
       else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_spheres_kernel<NT, false, false>, NT, rb, false);
+    } else if (variant == 1025) {  // 4 waves per SIMD: rings + linked ops in LDS, spheres read from L2
+      constexpr int NT = 1024;
+      size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp);
+      rc = want_stats ? launch(rtiow_wave_kernel<NT, 2, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 2, false>, NT, rb, false);
     } else if (variant == 768) RL_LAUNCH_WAVE(768)
     else if (variant == 1024) RL_LAUNCH_WAVE(1024)
     else if (variant == 256) RL_LAUNCH_WAVE(256)

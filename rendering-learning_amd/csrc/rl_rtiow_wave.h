@@ -128,12 +128,13 @@ __device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, dou
   return diff > 0.0;
 }
 
-template <int NT, bool LDS_SCENE, bool STATS>
+// LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2
+template <int NT, int LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
-  const size_t scene_lds = LDS_SCENE ? ((size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere)) : 0;
+  const size_t scene_lds = LDS_SCENE ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0)) : 0;
   unsigned long long *s_rng = (unsigned long long *)(smem + scene_lds);  // [16][NT]
   const unsigned char *opbase = (const unsigned char *)P.lops;  // pc is an index (HBM) or a byte offset (LDS) into this
   const DevSphere *spheres = P.spheres;
@@ -150,12 +151,14 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
       }
       l[i] = v;
     }
-    g = (const uint4 *)P.spheres;
-    l = (uint4 *)s_sph;
-    for (uint32_t i = tid; i < P.n_spheres * 4u; i += NT) l[i] = g[i];
+    if (LDS_SCENE == 1) {
+      g = (const uint4 *)P.spheres;
+      l = (uint4 *)s_sph;
+      for (uint32_t i = tid; i < P.n_spheres * 4u; i += NT) l[i] = g[i];
+      spheres = s_sph;
+    }
     __syncthreads();
     opbase = smem;
-    spheres = s_sph;
   }
   const uint32_t entry0 = LDS_SCENE ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6)) : P.entry0;
   const rl_rtiow_camera &cam = P.cam;
