@@ -52,11 +52,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # RL_BENCH_REHEARSAL=1: every rank uses GPU 0 and the gather goes over gloo through host memory — a way to run the
+    # N-rank code path on a one-GPU box (not a measurement; the JSON line says so)
+    rehearsal = os.environ.get("RL_BENCH_REHEARSAL") == "1" and world_size > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     rl = importlib.import_module("rendering-learning_amd")
     sharding = importlib.import_module("rendering-learning_amd.sharding")
@@ -79,10 +87,18 @@ def main():
     frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream(dev)
 
+    def exchange():  # the one exchange step of the path: framebuffer rows -> rank 0 over RCCL/xGMI
+        if rehearsal:
+            full = sharding.gather_frame(shard.cpu(), H, rank, G)
+            if rank == 0:
+                frame.copy_(full)
+        else:
+            sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
+
     def step(stats=None):
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step, stats=stats)
-        if G > 1:  # the one exchange step of the path: framebuffer rows -> rank 0 over RCCL/xGMI
-            sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
+        if G > 1:
+            exchange()
 
     # ---- counters for this exact workload (deterministic: identical for every launch) — untimed
     st = {}
@@ -102,7 +118,7 @@ def main():
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step)
         evs[k][1].record(stream)
         if G > 1:
-            sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
+            exchange()
     torch.cuda.synchronize(dev)
     if world_size > 1:
         dist.barrier()
@@ -111,7 +127,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
 
     tot = torch.tensor([float(st["rays"]), float(st["node_tests"]), float(st["sphere_tests"]), elapsed, kernel_ms],
-                       dtype=torch.float64, device=dev)
+                       dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world_size > 1:
         mx = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -156,6 +172,13 @@ def main():
         }
         if args.emulate_shard > 1:
             out["config"]["emulated_shard_of"] = args.emulate_shard
+        if rehearsal:
+            out["config"]["rehearsal"] = "all ranks on GPU 0, gloo gather through host memory: NOT a measurement"
+            # the assembled frame must equal a single-rank render of the same frame
+            ref = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+            cam.render_device(world, ref.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            out["config"]["rehearsal_frame_equal"] = bool(torch.equal(ref, frame))
         if world_size == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             oracle = importlib.import_module("rl_oracle")
