@@ -434,9 +434,21 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
     } else if (variant == 4) {
-      constexpr int NT = 768;
-      size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
-      rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
+      int gnt = 512;  // 2 waves per SIMD with 256 VGPRs: at 768 lanes (168 VGPRs) the kernel spills ~0.5 KB per lane to scratch and runs 2.3x slower on cfg 4
+      if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);  // A/B only
+      if (gnt == 512) {
+        constexpr int NT = 512;
+        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
+        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
+      } else if (gnt == 1024) {
+        constexpr int NT = 1024;
+        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
+        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
+      } else {
+        constexpr int NT = 768;
+        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
+        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
+      }
     } else if (variant == 5) {
       constexpr int NT = 512;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);

@@ -30,10 +30,10 @@ __device__ __forceinline__ D3 mat3_mul(const double *m, D3 v) {  // matrix.rs:42
 
 struct Rec {  // hittable/mod.rs:24-30 HitRecord + the material id
   D3 p, normal;
-  double t, u, v;
+  double t, u, v, w;  // uv3: (u, v, w) hold the object-space outward normal of a sphere whose UVs are still to be derived
   uint32_t mat;
   uint32_t pc;  // op where it was found (instance scope test)
-  bool front, any;
+  bool front, any, uv3;
 };
 
 __device__ __forceinline__ void face_normal(D3 d, D3 outward, D3 &normal, bool &front) {  // hittable/mod.rs:32-38
@@ -61,8 +61,11 @@ __device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payl
   D3 p = o + d * t;
   D3 outward = (p - center) * s.inv_r;
   double l2 = len2(outward);
-  r.t = t, r.p = p, r.u = 0.0, r.v = 0.0, r.mat = mat, r.pc = pc, r.any = true;
-  if (payload & SPH_UV) sphere_uv(outward, r.u, r.v);  // only spheres whose texture tree samples an Image (sphere.rs:70)
+  r.t = t, r.p = p, r.u = 0.0, r.v = 0.0, r.w = 0.0, r.mat = mat, r.pc = pc, r.any = true;
+  // get_sphere_uv (sphere.rs:70) is needed only by spheres whose texture tree samples an Image, and only for the hit that
+  // wins: keep its argument and evaluate acos / atan2 in SHADE (rec_uv) — in LEAF they cost ~70 VGPRs of pressure
+  r.uv3 = (payload & SPH_UV) != 0u;
+  if (r.uv3) r.u = outward.x, r.v = outward.y, r.w = outward.z;
   face_normal(d, outward, r.normal, r.front);
   return !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
 }
@@ -98,9 +101,15 @@ __device__ __forceinline__ bool planar_hit_rec(const DevPlanar &pl, uint32_t pc,
       vv = pl.uvs[1] * frac1 + pl.uvs[3] * frac2 + pl.uvs[5] * frac3;
     }
   }
-  r.t = t, r.p = p, r.u = uu, r.v = vv, r.mat = pl.material, r.pc = pc, r.any = true;
+  r.t = t, r.p = p, r.u = uu, r.v = vv, r.uv3 = false, r.mat = pl.material, r.pc = pc, r.any = true;
   face_normal(d, n, r.normal, r.front);
   return flag;
+}
+
+// the (u, v) the winning hit's texture lookup sees
+__device__ __forceinline__ void rec_uv(const Rec &r, double &u, double &v) {
+  u = r.u, v = r.v;
+  if (r.uv3) sphere_uv(d3(r.u, r.v, r.w), u, v);
 }
 
 // transform the world ray through the chain of PUSH ops that ends at `push_pc` (NONE: identity)
@@ -171,7 +180,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
       for (uint32_t depth = cam.max_depth; depth > 0; depth--) {
         c_rays++;
         Rec rec;
-        rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.front = true;
+        rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false, rec.front = true;
         rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
         D3 o = wo, d = wd;
         RayAux ra = ray_aux(o, d);
@@ -266,6 +275,14 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           break;
         }
         const DevMaterial &m = P.materials[rec.mat];
+          // texture first (it draws no random numbers): the transcendental code in here (acos / atan2 for sphere UVs, sin and
+          // Perlin for Noise) is register-hungry, so it runs before the scatter temporaries are live
+          D3 texc = d3(0.0, 0.0, 0.0);
+          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+            double tu, tv;
+            rec_uv(rec, tu, tv);
+            texc = texture_value<true>(P, m.texture, tu, tv, rec.p);
+          }
         uint32_t kind = m.kind;
         D3 normal = rec.normal, p = rec.p;
         D3 nd;
@@ -273,7 +290,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           D3 dir = normal + rc.unit_sphere(rng);
           bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
           nd = near_zero ? normal : dir;
-          thr = thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
+          thr = thr * texc;
         } else if (kind == RL_MAT_METAL) {
           D3 reflected = wd - normal * (2.0 * dot(wd, normal));
           nd = normalize(reflected) + rc.unit_sphere(rng) * m.fuzz;
@@ -306,7 +323,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
             nd = perp + par;
           }
         } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-          color = color + thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
+          color = color + thr * texc;
           break;
         } else {
           break;

@@ -190,11 +190,13 @@ __device__ __forceinline__ double perlin_noise(const rl_perlin &pn, D3 p) {
   double vv = v * v * (3.0 - 2.0 * v);
   double ww = w * w * (3.0 - 2.0 * w);
   double accum = 0.0;
-#pragma unroll
+  // deliberately NOT unrolled: eight live corner vectors cost the all-primitives kernels ~70 VGPRs (and with them their
+  // occupancy or scratch spills); one corner at a time accumulates in the reference's order just the same
+#pragma unroll 1
   for (uint32_t di = 0; di < 2; di++)
-#pragma unroll
+#pragma unroll 1
     for (uint32_t dj = 0; dj < 2; dj++)
-#pragma unroll
+#pragma unroll 1
       for (uint32_t dk = 0; dk < 2; dk++) {
         uint32_t h = pn.perm_x[(i + di) & 255u] ^ pn.perm_y[(j + dj) & 255u] ^ pn.perm_z[(k + dk) & 255u];
         D3 c = ld3(pn.randvec[h & 255u]);

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
   RayAux ra = ray_aux(o, d);
   double time = 0.0;
   Rec rec;
-  rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.front = true;
+  rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false, rec.front = true;
   rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
   uint32_t pc = 0, depth = 0;
   uint32_t c_rays = 0, c_flag = 0;
@@ -228,13 +228,21 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
           path_done = true;
         } else {
           const DevMaterial &m = P.materials[rec.mat];
+          // texture first (it draws no random numbers): the transcendental code in here (acos / atan2 for sphere UVs, sin and
+          // Perlin for Noise) is register-hungry, so it runs before the scatter temporaries are live
+          D3 texc = d3(0.0, 0.0, 0.0);
+          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+            double tu, tv;
+            rec_uv(rec, tu, tv);
+            texc = texture_value<true>(P, m.texture, tu, tv, rec.p);
+          }
           uint32_t kind = m.kind;
           D3 normal = rec.normal;
           if (kind == RL_MAT_LAMBERTIAN) {
             D3 dir = normal + rng.unit_sphere();
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;
-            thr = thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
+            thr = thr * texc;
           } else if (kind == RL_MAT_METAL) {
             D3 reflected = wd - normal * (2.0 * dot(wd, normal));
             nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
               nd = perp + par;
             }
           } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-            sum = sum + thr * texture_value<true>(P, m.texture, rec.u, rec.v, p);
+            sum = sum + thr * texc;
             path_done = true;
           } else {
             path_done = true;
