@@ -264,6 +264,7 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
       return RL_E_INVALID;
     }
     p.sphere_uv.push_back(mat_uv[s.material]);
+    if (mat_uv[s.material]) p.has_sphere_uv = true;
     DevSphere ds{};
     for (int k = 0; k < 3; k++) {
       ds.c0[k] = s.center0[k];

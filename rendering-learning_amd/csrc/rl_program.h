@@ -85,7 +85,7 @@ struct RtiowProgram {
   std::vector<float> image_pool;
   std::vector<rl_perlin> perlins;
   std::vector<uint8_t> sphere_uv;  // per sphere: texture tree reaches an Image
-  bool has_planars = false, has_instances = false, has_images = false, has_noise = false;
+  bool has_planars = false, has_instances = false, has_images = false, has_noise = false, has_sphere_uv = false;
   uint32_t max_instance_depth = 0;
 };
 

@@ -434,21 +434,17 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
     } else if (variant == 4) {
-      int gnt = 512;  // 2 waves per SIMD with 256 VGPRs: at 768 lanes (168 VGPRs) the kernel spills ~0.5 KB per lane to scratch and runs 2.3x slower on cfg 4
-      if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);  // A/B only
-      if (gnt == 512) {
-        constexpr int NT = 512;
-        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
-        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
-      } else if (gnt == 1024) {
-        constexpr int NT = 1024;
-        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
-        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
-      } else {
-        constexpr int NT = 768;
-        size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
-        rc = want_stats ? launch(rtiow_wave_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_wave_general_kernel<NT, false>, NT, rb, false);
-      }
+      // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of
+      // scenes that have Noise textures or Image textures on spheres).  At 768 lanes (168 VGPRs) the spills land in the TRAV
+      // loop and cost 2.3x (measured, cfg 4: 1101 vs 465 Mrays/s).  RL_GENERAL_NT=768 overrides (A/B only).
+      bool trans = scene->rt.has_noise || scene->rt.has_sphere_uv;
+      int gnt = 512;
+      if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);
+      size_t rb = (size_t)16 * gnt * sizeof(unsigned long long);
+      if (trans && gnt == 768) rc = want_stats ? launch(rtiow_wave_general_kernel<768, true, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, true, false>, 768, rb, false);
+      else if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, true, false>, 512, rb, false);
+      else if (gnt == 512) rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, false, false>, 512, rb, false);
+      else rc = want_stats ? launch(rtiow_wave_general_kernel<768, false, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, false, false>, 768, rb, false);
     } else if (variant == 5) {
       constexpr int NT = 512;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);

@@ -107,9 +107,10 @@ __device__ __forceinline__ bool planar_hit_rec(const DevPlanar &pl, uint32_t pc,
 }
 
 // the (u, v) the winning hit's texture lookup sees
+template <bool SPH_UVS = true>
 __device__ __forceinline__ void rec_uv(const Rec &r, double &u, double &v) {
   u = r.u, v = r.v;
-  if (r.uv3) sphere_uv(d3(r.u, r.v, r.w), u, v);
+  if (SPH_UVS && r.uv3) sphere_uv(d3(r.u, r.v, r.w), u, v);
 }
 
 // transform the world ray through the chain of PUSH ops that ends at `push_pc` (NONE: identity)
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
           if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
             double tu, tv;
             rec_uv(rec, tu, tv);
-            texc = texture_value<true>(P, m.texture, tu, tv, rec.p);
+            texc = texture_value<2>(P, m.texture, tu, tv, rec.p);
           }
         uint32_t kind = m.kind;
         D3 normal = rec.normal, p = rec.p;

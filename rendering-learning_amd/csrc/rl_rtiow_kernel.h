@@ -229,9 +229,10 @@ __device__ __forceinline__ void sphere_uv(D3 p, double &u, double &v) {
   v = theta / PI;
 }
 
-// texture.rs: value(u, v, p).  FULL = false compiles the Noise and Image branches out (the sphere-only kernels never
-// see them: scenes with Noise / Image textures are routed to the all-primitives kernels by rl_rtiow_render_device).
-template <bool FULL = false>
+// texture.rs: value(u, v, p).  MODE 0 = Solid / Checker only (the sphere-only kernels: scenes with Image / Noise textures
+// are routed to the all-primitives kernels by rl_rtiow_render_device), 1 = + Image, 2 = + Noise.  The branches are
+// compiled out, not just skipped: sin() and the Perlin code cost the kernels that carry them ~70 VGPRs.
+template <int MODE = 0>
 __device__ __forceinline__ D3 texture_value(const RtiowParams &P, uint32_t tex, double u, double v, D3 p) {
   for (int guard = 0; guard < 64; guard++) {
     const DevTexture &t = P.textures[tex];
@@ -245,8 +246,8 @@ __device__ __forceinline__ D3 texture_value(const RtiowParams &P, uint32_t tex, 
       tex = ((sum % 2) == 0) ? t.even : t.odd;
       continue;
     }
-    if (!FULL) return D3{0.0, 0.0, 0.0};
-    if (t.kind == RL_TEX_NOISE) {  // texture.rs:84-94: Color(0.5,0.5,0.5) * (1 + sin(scale * p.z + 10 * turb(p, 7)))
+    if (MODE == 0) return D3{0.0, 0.0, 0.0};
+    if (MODE == 2 && t.kind == RL_TEX_NOISE) {  // texture.rs:84-94: Color(0.5,0.5,0.5) * (1 + sin(scale * p.z + 10 * turb(p, 7)))
       double sv = 1.0 + sin(t.inv_scale * p.z + 10.0 * perlin_turb(P.perlins[t.image], p, 7u));
       return D3{0.5 * sv, 0.5 * sv, 0.5 * sv};
     }

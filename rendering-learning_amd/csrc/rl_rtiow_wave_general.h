@@ -16,7 +16,9 @@ namespace rl {
 
 enum : uint32_t { ST_XF = 6 };
 
-template <int NT, bool STATS>
+// TRANS: the scene needs the transcendental texture code (Noise, or Image textures on spheres -> get_sphere_uv); without it
+// the kernel fits 168 VGPRs (3 waves per SIMD) instead of 256 (2 waves per SIMD)
+template <int NT, bool TRANS, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -233,8 +235,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
           D3 texc = d3(0.0, 0.0, 0.0);
           if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
             double tu, tv;
-            rec_uv(rec, tu, tv);
-            texc = texture_value<true>(P, m.texture, tu, tv, rec.p);
+            rec_uv<TRANS>(rec, tu, tv);
+            texc = texture_value<(TRANS ? 2 : 1)>(P, m.texture, tu, tv, rec.p);
           }
           uint32_t kind = m.kind;
           D3 normal = rec.normal;
