@@ -145,15 +145,16 @@ def main():
         alg_bytes = (64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 208.0 * st["rays"])
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         launches = 2 if (args.spp >= 64 and os.environ.get("RL_LPT", "1") != "0") else 1
-        traffic = None
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world_size == 1 and not args.emulate_shard:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == f"{W}x{H}x{args.spp}spp_d{args.depth}":
                     traffic = tj.get("hbm_bytes_per_launch")
+                    valu = tj.get("valu")  # SQ counters of the same kernel (profiles/): what actually binds it
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         out = {
             "metric": "Mrays/sec (primary+secondary), 1080p 1024spp depth50; 1/2/4/8 GPU",
             "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +169,8 @@ def main():
                          # spp >= 64: one render = two launches of the same kernel (8-sample cost probe + cost-sorted remainder);
                          # kernel_ms spans both, so rocprofv3's per-launch average = kernel_ms / launches_per_step
                          "launches_per_step": launches, "kernel_avg_launch_ms": kernel_ms / launches,
-                         "note": "scene is LDS-resident: real HBM traffic is the framebuffer; practical ceiling is FP64 VALU issue under divergence"},
+                         "valu_counters": valu,
+                         "note": "scene is LDS / L2-resident: real HBM traffic is the framebuffer; the binding resource is VALU issue under divergence (valu_counters)"},
         }
         if args.emulate_shard > 1:
             out["config"]["emulated_shard_of"] = args.emulate_shard
