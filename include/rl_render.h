@@ -17,7 +17,9 @@
  * Conventions: plain pointers and sizes only; 0 on success, negative RL_E_* otherwise; the
  * library never unwinds or aborts across the boundary (every reference panic site becomes an
  * error code or a flagged-pixel count); scene_create deep-copies, so the caller may free its
- * arrays as soon as it returns; an rl_scene is immutable; the caller owns all host pointers.
+ * arrays as soon as it returns; an rl_scene's program is immutable but it owns per-render scratch
+ * (counters, the cost-sorted tile order), so renders of ONE scene must not overlap — use one scene
+ * handle per concurrent render; the caller owns all host pointers.
  * Everything is IEEE binary64 unless stated.  There is NO CPU fallback: without a GPU / without
  * the HIP code object every compute entry point fails with RL_E_NO_DEVICE.
  */
