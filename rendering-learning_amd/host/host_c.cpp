@@ -346,6 +346,44 @@ int rlh_canvas_from_bincode(const uint8_t *bytes, uint64_t len, uint64_t *sample
   }
 }
 
+// ------------------------------------------------------------------ the reference's integration tests, end to end in C++
+// tests/ray_tracing_one_weekend.rs:77-95: scene -> Camera::new(params).render(&world) -> output_ppm, through the
+// C++ mirror (Camera::render in host_render.cpp calls the C ABI).  Returns the PPM text (rlh_free) or NULL.
+char *rlh_rtiow_run_golden_test(int from_checkpoint, uint64_t *len) {
+  try {
+    scenes::RtiowScene s = scenes::golden_test_scene();
+    if (!from_checkpoint) {
+      rtiow::Canvas c = rtiow::Camera(s.params).render(*s.world);
+      return dup_string(rtiow::output_ppm(c), len);
+    }
+    // tests/ray_tracing_one_weekend.rs:118-162: render half the samples, round-trip the checkpoint through bincode, resume
+    rtiow::CameraParams half = s.params;
+    half.samples_per_pixel = s.params.samples_per_pixel / 2;
+    rtiow::Canvas first = rtiow::Camera(half).render(*s.world);
+    std::vector<uint8_t> bytes = rtiow::canvas_to_bincode(first);
+    rtiow::Canvas checkpoint = rtiow::canvas_from_bincode(bytes.data(), bytes.size());
+    rtiow::CameraParams rest = s.params;
+    rest.samples_per_pixel = s.params.samples_per_pixel - half.samples_per_pixel;
+    rtiow::Canvas c = rtiow::Camera(rest).render_from_checkpoint(*s.world, checkpoint);
+    return dup_string(rtiow::output_ppm(c), len);
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+// tests/ray_tracer.rs:242-275 (which = 0, needs the OBJ text), :56-240 mirror (1), :277-368 csg (2): Camera::render -> Canvas::ppm
+char *rlh_rtc_run_golden_test(int which, const char *obj_text, uint64_t obj_len, uint64_t *len) {
+  try {
+    scenes::RtcScene s = which == 0 ? scenes::rtc_test_obj_scene(std::string(obj_text, obj_len))
+                                    : (which == 1 ? scenes::rtc_test_mirror_scene() : scenes::rtc_test_csg_scene());
+    rtc::Canvas c = s.camera->render(s.world, rtc::RenderOpts{});
+    return dup_string(rtc::canvas_ppm(c), len);
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
 // ------------------------------------------------------------------ RTC
 struct rlh_rtc {
   rtc::Flattened flat;
