@@ -57,6 +57,7 @@ struct alignas(16) DevPlanar {  // 128 B core (plane.rs:12-20) + optional per-ve
   double pad;
 };
 
+static const uint32_t MAT_TEX_SOLID = 0x100u;  // flag in a flattened per-sphere material's kind: albedo holds the Solid texture's colour
 struct DevMaterial {  // 48 B
   uint32_t kind, texture;
   double albedo[3];

@@ -82,6 +82,7 @@ struct rl_scene {
   RtiowProgram rt;
   DevOp *d_ops = nullptr;
   DevOp *d_lops = nullptr;  // linked form of the ops for the wave kernel (sphere-only scenes)
+  DevMaterial *d_sphere_flat = nullptr;  // per-sphere flattened materials for the wave kernel
   uint32_t entry0 = 0;
   DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
@@ -170,7 +171,7 @@ int rl_device_info(char *name, int cap) {
 
 void rl_scene_destroy(rl_scene *s) {
   if (!s) return;
-  hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
+  hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
@@ -215,6 +216,29 @@ static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out)
   return ops.empty() ? (uint32_t)(ST_SHADE << 29) : entry(0);
 }
 
+// One DevMaterial per sphere for the wave kernel's SHADE: the sphere's material with (a) a Solid texture's colour copied
+// into albedo (flag MAT_TEX_SOLID) and (b) for a Dielectric albedo = {1/ior, r0(ri = 1/ior), r0(ri = ior)} with
+// r0 = ((1 - ri) / (1 + ri))^2 — the very expressions material.rs:140-166 evaluates per scatter (IEEE, no contraction).
+static void flatten_sphere_materials(const RtiowProgram &rt, std::vector<DevMaterial> &out) {
+  out.resize(rt.spheres.size());
+  for (size_t i = 0; i < rt.spheres.size(); i++) {
+    DevMaterial m = rt.materials[rt.sphere_material[i]];
+    if ((m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) && rt.textures[m.texture].kind == RL_TEX_SOLID) {
+      const DevTexture &t = rt.textures[m.texture];
+      m.albedo[0] = t.color[0], m.albedo[1] = t.color[1], m.albedo[2] = t.color[2];
+      m.kind |= MAT_TEX_SOLID;
+    } else if (m.kind == RL_MAT_DIELECTRIC) {
+      auto r0 = [](double ri) {
+        double q = (1.0 - ri) / (1.0 + ri);
+        return q * q;
+      };
+      double inv = 1.0 / m.ior;
+      m.albedo[0] = inv, m.albedo[1] = r0(inv), m.albedo[2] = r0(m.ior);
+    }
+    out[i] = m;
+  }
+}
+
 rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
   if (!g_ready) {
     set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
@@ -243,7 +267,9 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
   if (!(s->rt.has_planars || s->rt.has_instances || s->rt.has_images || s->rt.has_noise) && s->rt.ops.size() < (1u << 29)) {
     std::vector<DevOp> lops;
     s->entry0 = link_ops(s->rt.ops, lops);
-    if (upload(lops, &s->d_lops) != RL_OK) {
+    std::vector<DevMaterial> flat;
+    flatten_sphere_materials(s->rt, flat);
+    if (upload(lops, &s->d_lops) != RL_OK || upload(flat, &s->d_sphere_flat) != RL_OK) {
       rl_scene_destroy(s);
       return nullptr;
     }
@@ -363,7 +389,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
   P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins;
   P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
-  P.lops = scene->d_lops, P.entry0 = scene->entry0;
+  P.lops = scene->d_lops, P.entry0 = scene->entry0, P.sphere_flat = scene->d_sphere_flat;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;

@@ -25,6 +25,7 @@ struct RtiowParams {
   const float *image_pool;
   const rl_perlin *perlins;
   uint32_t n_ops, n_spheres;
+  const DevMaterial *sphere_flat;  // wave kernel: per-sphere flattened material (see flatten_sphere_materials)
   const DevOp *lops;  // wave kernel: ops with {code, skip} replaced by linked successor words (state << 29 | op index), see link_ops
   uint32_t entry0;    // linked word of op 0: where (and in which state) a new ray starts
   rl_rtiow_camera cam;

@@ -344,8 +344,12 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           D3 outward = (p - center) * s.inv_r;
           bool front = dot(d, outward) <= 0.0;
           D3 normal = front ? outward : -outward;
-          const DevMaterial &m = P.materials[P.sphere_material[si]];
-          uint32_t kind = m.kind;
+          // one flattened record per sphere (rl_render.hip flatten_sphere_materials): the material with a Solid texture's
+          // colour inlined, and for a Dielectric the constants 1/ior and Schlick's r0 of both orientations — one load
+          // instead of the sphere -> material -> texture chain, same values bit for bit
+          const DevMaterial &m = P.sphere_flat[si];
+          const uint32_t kind = m.kind & 0xFFu;
+          const bool solid = (m.kind & MAT_TEX_SOLID) != 0u;
           // shared sub-expressions, evaluated once per block instead of once per material branch (same values, same
           // RNG order: the unit-sphere draw is the first draw of both Lambertian and Metal scatter)
           const bool is_lamb = kind == RL_MAT_LAMBERTIAN, is_metal = kind == RL_MAT_METAL, is_diel = kind == RL_MAT_DIELECTRIC;
@@ -360,13 +364,13 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             D3 dir = normal + us;
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;
-            thr = thr * texture_value(P, m.texture, 0.0, 0.0, p);
+            thr = thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
           } else if (is_metal) {
             nd = vn + us * m.fuzz;
             if (!(dot(nd, normal) > 0.0)) path_done = true;  // absorbed
             else thr = thr * ld3(m.albedo);
           } else if (is_diel) {
-            double ri = front ? 1.0 / m.ior : m.ior;
+            double ri = front ? m.albedo[0] : m.ior;  // albedo[0] = 1.0 / ior
             D3 ud = vn;
             if (approx_eq_eps(m2, 0.0, 1e-16)) {
               c_flag++;
@@ -376,8 +380,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
             bool reflect = ri * sin_theta > 1.0;
             if (!reflect) {
-              double q = (1.0 - ri) / (1.0 + ri);
-              double r0 = q * q;
+              double r0 = front ? m.albedo[1] : m.albedo[2];  // ((1 - ri) / (1 + ri))^2 for ri = 1/ior and ri = ior
               double xx = 1.0 - cos_theta;
               double x2 = xx * xx;
               double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
               nd = perp + par;
             }
           } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-            sum = sum + thr * texture_value(P, m.texture, 0.0, 0.0, p);
+            sum = sum + thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
             path_done = true;
           } else {
             path_done = true;  // Flat
