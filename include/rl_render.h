@@ -194,6 +194,18 @@ typedef struct rl_rtiow_camera {
 
 rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc);
 
+/* Bvh::new (bvh.rs:22-60) on the device, for worlds too big to build comfortably on the host (1 M spheres: seconds).
+ * Input: n hittables as their bounding boxes (6 doubles each: x.min, x.max, y.min, y.max, z.min, z.max = what
+ * Hittable::bounding_box() returns, already padded by AABB::new) and their hrefs.  Output: the nodes in the order the
+ * reference's recursion creates them (node, left subtree, right subtree; node 0 is the root): box = merge of the boxes
+ * below (aabb.rs:135), split on the longest axis (bvh.rs:63-77) after a STABLE sort by `box.axis.min` under
+ * f64::total_cmp (bvh.rs:49 uses sort_unstable_by: the order of equal keys is implementation-defined there), left half =
+ * the first len / 2, leaves of 1-2 hittables.  Inner nodes reference their children as RL_H_BVH node_base + index, so the
+ * records can be appended to a scene's bvh_nodes at position node_base.  *out_n_nodes receives the node count (also
+ * when cap is too small: RL_E_INVALID).  Host pointers. */
+int rl_bvh_build(const double *prim_boxes, const rl_href *prims, uint32_t n, uint32_t node_base, rl_bvh_node *out_nodes,
+                 uint32_t cap, uint32_t *out_n_nodes);
+
 /* Replaces Camera::render / render_from_checkpoint's _render(first_sample, world).
  * out_rgb_sum: caller-owned host buffer, W*H*3 doubles, row-major, holds SUMS over samples
  * exactly like Canvas.data (camera.rs:269). */

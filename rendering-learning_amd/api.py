@@ -147,7 +147,7 @@ def host_lib():
 
 # every symbol include/rl_render.h declares (checked by tests/test_abi.py)
 RENDER_SYMBOLS = ["rl_init", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info", "rl_scene_destroy",
-                  "rl_rtiow_scene_create", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
+                  "rl_rtiow_scene_create", "rl_bvh_build", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
                   "rl_rtiow_encode_rgb8_device", "rl_rtiow_render_rgb8",
                   "rl_rtc_scene_create", "rl_rtc_render", "rl_rtc_render_rows", "rl_rtc_render_device",
                   "rl_rtc_encode_rgb8_device", "rl_rtc_render_rgb8"]
@@ -290,16 +290,19 @@ class World:
         return World(L.rlh_rtiow_earth_scene(rgb8.ctypes.data, w, h))
 
     @staticmethod
-    def stress_scene(n_side=1000, subdiv=2, obj_text: bytes = None, rgb8: np.ndarray = None, seed=5):
-        """BASELINE configs[4]: n_side^2 small spheres + ground + subdivided spot mesh (see host/scenes.hpp)."""
+    def stress_scene(n_side=1000, subdiv=2, obj_text: bytes = None, rgb8: np.ndarray = None, seed=5, device_bvh=False):
+        """BASELINE configs[4]: n_side^2 small spheres + ground + subdivided spot mesh (see host/scenes.hpp).
+        device_bvh: build both BVHs with rl_bvh_build on the GPU instead of the host recursion (same tree)."""
         L = host_lib()
         L.rlh_rtiow_stress_scene.restype = C.c_void_p
-        L.rlh_rtiow_stress_scene.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.rlh_rtiow_stress_scene.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+        if device_bvh and not _inited:
+            init()
         if obj_text is None:
-            return World(L.rlh_rtiow_stress_scene(n_side, subdiv, None, 0, None, 0, 0, seed))
+            return World(L.rlh_rtiow_stress_scene(n_side, subdiv, None, 0, None, 0, 0, seed, int(device_bvh)))
         rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
         h, w = rgb8.shape[:2]
-        return World(L.rlh_rtiow_stress_scene(n_side, subdiv, obj_text, len(obj_text), rgb8.ctypes.data, w, h, seed))
+        return World(L.rlh_rtiow_stress_scene(n_side, subdiv, obj_text, len(obj_text), rgb8.ctypes.data, w, h, seed, int(device_bvh)))
 
     @staticmethod
     def from_spheres(spheres, materials, textures, use_bvh):

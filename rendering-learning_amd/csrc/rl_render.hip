@@ -76,6 +76,10 @@ __global__ void encode_rtc_rgb8(const double *rgb, unsigned long long n_vals, un
 
 }  // namespace
 
+namespace rl {
+int set_err_public(int code, const std::string &m) { return set_err(code, m); }  // for rl_bvh_build.hip
+}  // namespace rl
+
 struct rl_scene {
   int kind;  // 1 = RTIOW, 2 = RTC
   // RTIOW

@@ -81,9 +81,9 @@ rlh_rtiow *rlh_rtiow_earth_scene(const uint8_t *rgb8, uint32_t w, uint32_t h) {
 }
 // BASELINE configs[4] stress scene (scenes.hpp::stress_scene); obj_text may be NULL (spheres only)
 rlh_rtiow *rlh_rtiow_stress_scene(int n_side, int subdiv, const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h,
-                                  uint64_t seed) {
+                                  uint64_t seed, int device_bvh) {
   try {
-    return finish(scenes::stress_scene(n_side, subdiv, obj_text ? std::string(obj_text, obj_len) : std::string(), rgb8, w, h, seed));
+    return finish(scenes::stress_scene(n_side, subdiv, obj_text ? std::string(obj_text, obj_len) : std::string(), rgb8, w, h, seed, device_bvh != 0));
   } catch (std::exception &e) {
     g_err = e.what();
     return nullptr;
@@ -339,6 +339,58 @@ int rlh_canvas_from_bincode(const uint8_t *bytes, uint64_t len, uint64_t *sample
   try {
     rtiow::Canvas c = rtiow::canvas_from_bincode(bytes, (size_t)len);
     *samples = c.samples, *width = c.width, *height = c.height, *n_pixels = c.data.size() / 3;
+    return 0;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// Bvh::new on the host (rtiow::Bvh) against rl_bvh_build on the device over the same hittables: n spheres (every 7th moving,
+// radii and centres from a small LCG; `ties` > 0 snaps the centres to a grid so that many sort keys are EQUAL and the
+// stable order matters) plus n / 4 triangles.  Returns 0 when every node record is identical (boxes bit for bit, same
+// children), else the 1-based index of the first differing node, or -1 on error.
+int64_t rlh_bvh_build_compare(uint32_t n, uint64_t seed, int ties) {
+  try {
+    using namespace rtiow;
+    uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      return (double)(st >> 11) * (1.0 / 9007199254740992.0);
+    };
+    auto coord = [&]() {
+      double v = rnd() * 40.0 - 20.0;
+      return ties > 0 ? std::floor(v / 4.0) * 4.0 : v;
+    };
+    auto mat = Lambertian(SolidColor(Color(0.5, 0.5, 0.5)));
+    std::vector<HittablePtr> hs;
+    for (uint32_t i = 0; i < n; i++) {
+      Point3 c(coord(), coord(), coord());
+      double r = 0.05 + rnd();
+      if (i % 7 == 3) hs.push_back(std::make_shared<Sphere>(Center::Moving(c, c + Vec3(rnd(), rnd(), rnd())), r, mat));
+      else hs.push_back(std::make_shared<Sphere>(Center::Stationary(c), r, mat));
+    }
+    for (uint32_t i = 0; i < n / 4; i++) {
+      Point3 q(coord(), coord(), coord());
+      Point3 pts[3] = {q, q + Vec3(rnd(), 0.0, rnd()), q + Vec3(0.0, rnd(), ties ? 0.0 : rnd())};
+      hs.push_back(std::make_shared<Triangle>(pts, nullptr, nullptr, mat));
+    }
+    Flattened fh, fd;
+    fh.root = Bvh(hs).flatten(fh);
+    fd.root = DeviceBvh(hs).flatten(fd);
+    if (fh.bvh_nodes.size() != fd.bvh_nodes.size()) return -1;
+    auto same_prim = [&](rl_href a, rl_href b) {
+      if (a.kind != b.kind) return false;
+      if (a.kind == RL_H_SPHERE) return std::memcmp(&fh.spheres[a.index], &fd.spheres[b.index], sizeof(rl_sphere)) == 0;
+      if (a.kind == RL_H_PLANAR) return std::memcmp(&fh.planars[a.index], &fd.planars[b.index], sizeof(rl_planar)) == 0;
+      return a.index == b.index;  // RL_H_BVH: both numberings are the recursion order
+    };
+    for (size_t k = 0; k < fh.bvh_nodes.size(); k++) {
+      const rl_bvh_node &a = fh.bvh_nodes[k], &b = fd.bvh_nodes[k];
+      bool ok = std::memcmp(a.bbox, b.bbox, sizeof a.bbox) == 0 && a.n_children == b.n_children;
+      for (uint32_t c = 0; ok && c < a.n_children; c++) ok = same_prim(a.child[c], b.child[c]);
+      if (!ok) return (int64_t)k + 1;
+    }
     return 0;
   } catch (std::exception &e) {
     g_err = e.what();

@@ -615,6 +615,37 @@ struct Bvh : Hittable {  // bvh.rs:11-60
   }
 };
 
+// Bvh::new evaluated on the DEVICE (rl_bvh_build): same tree as `Bvh` above — same boxes, same
+// split axes, same stable order — for worlds where the host recursion takes seconds (1 M spheres).  The hittables are
+// flattened first (in the caller's order), then the node records are appended after them.
+struct DeviceBvh : Hittable {
+  std::vector<HittablePtr> hittables;
+  explicit DeviceBvh(std::vector<HittablePtr> hs) : hittables(std::move(hs)) {
+    if (hittables.empty()) throw std::runtime_error("Cannot make a BVH node without hittables.");
+  }
+  AABB bounding_box() const override {
+    AABB b = AABB::empty();
+    for (auto &h : hittables) b = b.merge(h->bounding_box());
+    return b;
+  }
+  rl_href flatten(Flattened &f) const override {
+    std::vector<rl_href> hrefs;
+    std::vector<double> boxes;
+    hrefs.reserve(hittables.size()), boxes.reserve(hittables.size() * 6);
+    for (auto &h : hittables) {
+      hrefs.push_back(h->flatten(f));
+      AABB b = h->bounding_box();
+      for (double v : {b.x.min, b.x.max, b.y.min, b.y.max, b.z.min, b.z.max}) boxes.push_back(v);
+    }
+    uint32_t base = (uint32_t)f.bvh_nodes.size(), count = 0;
+    f.bvh_nodes.resize((size_t)base + 2 * hittables.size());
+    int rc = rl_bvh_build(boxes.data(), hrefs.data(), (uint32_t)hittables.size(), base, f.bvh_nodes.data() + base, (uint32_t)(2 * hittables.size()), &count);
+    if (rc != RL_OK) throw std::runtime_error(std::string("rl_bvh_build: ") + rl_last_error());
+    f.bvh_nodes.resize((size_t)base + count);
+    return rl_href{RL_H_BVH, base};
+  }
+};
+
 // ---------------------------------------------------------------- camera.rs
 struct CameraParams {  // camera.rs:23-59 (defaults as in the reference)
   double aspect_ratio = 1.0;

@@ -348,7 +348,7 @@ inline RtiowScene earth_scene(const uint8_t *rgb8, uint32_t tw, uint32_t th) {
 // (4,0.2,0) exclusion; Xoshiro256++ seed 5.  Camera: bouncing_spheres' (caller sets W / spp / depth).
 // Only the CPU oracle pins this config.
 inline RtiowScene stress_scene(int n_side, int subdiv, const std::string &obj_text, const uint8_t *rgb8, uint32_t tw, uint32_t th,
-                               uint64_t seed = 5) {
+                               uint64_t seed = 5, bool device_bvh = false) {
   using namespace rtiow;
   auto rng = Xoshiro256PlusPlus::seed_from_u64(seed);
   std::vector<HittablePtr> world;
@@ -412,7 +412,7 @@ inline RtiowScene stress_scene(int n_side, int subdiv, const std::string &obj_te
     }
     std::vector<HittablePtr> ths;
     for (auto &t : tris) ths.push_back(std::make_shared<Triangle>(t.p, t.has_uv ? t.uv : nullptr, nullptr, surface));
-    auto mesh = std::make_shared<Bvh>(std::move(ths));
+    HittablePtr mesh = device_bvh ? HittablePtr(std::make_shared<DeviceBvh>(std::move(ths))) : HittablePtr(std::make_shared<Bvh>(std::move(ths)));
     world.push_back(std::make_shared<Translate>(Transform::rotate_y(Transform::scale(mesh, 10.0), 45.0), Vec3(0.0, 8.25, 0.0)));
   }
   CameraParams p;
@@ -426,6 +426,7 @@ inline RtiowScene stress_scene(int n_side, int subdiv, const std::string &obj_te
   p.vup = Vec3(0.0, 1.0, 0.0);
   p.defocus_angle = 0.6;
   p.focus_dist = 10.0;
+  if (device_bvh) return RtiowScene{std::make_shared<DeviceBvh>(std::move(world)), p};
   return RtiowScene{std::make_shared<Bvh>(std::move(world)), p};
 }
 
