@@ -96,6 +96,37 @@ uint32_t count_nodes(uint32_t n, std::unordered_map<uint32_t, uint32_t> &memo) {
 
 }  // namespace
 
+namespace rl {
+// Cost-sorted launch order of rl_rtiow_render_device, on the device: order = tile ids sorted by cost, most expensive first,
+// ties in ascending tile id (what std::stable_sort(order, cost[a] > cost[b]) gives).  keys_tmp / order_in: n u32 each;
+// *temp / *temp_bytes: scratch owned by the caller, grown on demand.  Asynchronous on `stream`.
+__global__ void iota_u32(uint32_t *p, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+int sort_tiles_by_cost_desc(const uint32_t *d_cost, uint32_t *d_keys_tmp, uint32_t *d_order_in, uint32_t *d_order_out, uint32_t n, void **temp, size_t *temp_bytes,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(iota_u32, dim3((n + 255) / 256), dim3(256), 0, stream, d_order_in, n);
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, d_cost, d_keys_tmp, d_order_in, d_order_out, (int)n, 0, 32, stream);
+  if (e != hipSuccess) return set_err_public(RL_E_DEVICE, std::string("tile sort (size query): ") + hipGetErrorString(e));
+  if (need > *temp_bytes) {
+    if (*temp) {
+      hipStreamSynchronize(stream);  // an earlier sort on this stream may still use the old buffer
+      hipFree(*temp);
+    }
+    *temp = nullptr, *temp_bytes = 0;
+    e = hipMalloc(temp, need);
+    if (e != hipSuccess) return set_err_public(RL_E_DEVICE, std::string("tile sort (temp storage): ") + hipGetErrorString(e));
+    *temp_bytes = need;
+  }
+  need = *temp_bytes;
+  e = hipcub::DeviceRadixSort::SortPairsDescending(*temp, need, d_cost, d_keys_tmp, d_order_in, d_order_out, (int)n, 0, 32, stream);
+  if (e != hipSuccess) return set_err_public(RL_E_DEVICE, std::string("tile sort: ") + hipGetErrorString(e));
+  return RL_OK;
+}
+}  // namespace rl
+
 extern "C" int rl_bvh_build(const double *prim_boxes, const rl_href *prims, uint32_t n, uint32_t node_base, rl_bvh_node *out_nodes, uint32_t cap,
                             uint32_t *out_n_nodes) {
   if (!prim_boxes || !prims || !out_nodes || n == 0) return rl::set_err_public(RL_E_INVALID, "rl_bvh_build: bad argument (Bvh::new needs at least one hittable)");

@@ -78,6 +78,8 @@ __global__ void encode_rtc_rgb8(const double *rgb, unsigned long long n_vals, un
 
 namespace rl {
 int set_err_public(int code, const std::string &m) { return set_err(code, m); }  // for rl_bvh_build.hip
+int sort_tiles_by_cost_desc(const uint32_t *d_cost, uint32_t *d_keys_tmp, uint32_t *d_order_in, uint32_t *d_order_out, uint32_t n, void **temp, size_t *temp_bytes,
+                            hipStream_t stream);  // rl_bvh_build.hip (hipCUB)
 }  // namespace rl
 
 struct rl_scene {
@@ -111,7 +113,9 @@ struct rl_scene {
   unsigned char *d_scratch = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
-  uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr;
+  uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_keys = nullptr, *d_tile_iota = nullptr;
+  void *d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
   size_t lpt_pix = 0, lpt_tiles = 0;
   // wavefront (v3) buffers: per-pixel state, ray and hit records, queues, control words
   PixState *wf_pix = nullptr;
@@ -178,7 +182,7 @@ void rl_scene_destroy(rl_scene *s) {
   hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
-  hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order);
+  hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
   hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns);
   hipFree(s->wf_pix), hipFree(s->wf_ray), hipFree(s->wf_hit), hipFree(s->wf_qtrav), hipFree(s->wf_qshade), hipFree(s->wf_qgen), hipFree(s->wf_ctl), hipFree(s->wf_class);
   if (s->ev0) hipEventDestroy(s->ev0);
@@ -526,23 +530,22 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       ms->lpt_pix = npix;
     }
     if (ms->lpt_tiles < ntiles) {
-      hipFree(ms->d_tile_cost), hipFree(ms->d_tile_order);
-      ms->d_tile_cost = ms->d_tile_order = nullptr, ms->lpt_tiles = 0;
+      hipFree(ms->d_tile_cost), hipFree(ms->d_tile_order), hipFree(ms->d_tile_keys), hipFree(ms->d_tile_iota);
+      ms->d_tile_cost = ms->d_tile_order = ms->d_tile_keys = ms->d_tile_iota = nullptr, ms->lpt_tiles = 0;
       HIP_TRY(hipMalloc((void **)&ms->d_tile_cost, ntiles * sizeof(uint32_t)));
       HIP_TRY(hipMalloc((void **)&ms->d_tile_order, ntiles * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void **)&ms->d_tile_keys, ntiles * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc((void **)&ms->d_tile_iota, ntiles * sizeof(uint32_t)));
       ms->lpt_tiles = ntiles;
     }
     HIP_TRY(hipMemsetAsync(ms->d_tile_cost, 0, ntiles * sizeof(uint32_t), stream));
     P.sample_end = lpt_first, P.pos_state = ms->d_pos, P.tile_cost = ms->d_tile_cost;
     rc = launch_variant();
     if (rc != RL_OK) return rc;
-    std::vector<uint32_t> cost(ntiles), order(ntiles);
-    HIP_TRY(hipMemcpyAsync(cost.data(), ms->d_tile_cost, ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (size_t i = 0; i < ntiles; i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-    HIP_TRY(hipMemcpyAsync(ms->d_tile_order, order.data(), ntiles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // `order` is a local: the copy must have left host memory
+    // tiles by cost, most expensive first, on the device (stable radix sort): the whole render stays asynchronous on `stream`
+    rc = rl::sort_tiles_by_cost_desc(ms->d_tile_cost, ms->d_tile_keys, ms->d_tile_iota, ms->d_tile_order, (uint32_t)ntiles, &ms->d_sort_temp, &ms->sort_temp_bytes,
+                                     stream);
+    if (rc != RL_OK) return rc;
     HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
