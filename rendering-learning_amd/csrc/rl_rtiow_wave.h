@@ -128,6 +128,36 @@ __device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, dou
   return diff > 0.0;
 }
 
+// Single-precision form of the filter, for LDS-resident ops whose box has been re-stored as six floats (round to nearest).
+//   inv32 = RN32(1/d), oi32 = RN32(o * (1/d)), t'' = fmaf(b32, inv32, -oi32), everything in binary32, u = 2^-24.
+// |b32*inv32 - b/d| <= 2.1u|b/d| <= 2.1u(|t| + |o/d|), |oi32 - o/d| <= 1.1u|o/d|, one more rounding in the fma, and the
+// clamp closest32 = RN32(closest) moves tmax by <= u|tmax|: each end of [tmin, tmax] is off by <= 3.2u|t| + 3.3u max|o/d|.
+// The decision tmin < tmax is therefore certain when |tmax''-tmin''| > 8u(|tmin''|+|tmax''|) + 16u max|oi32| (twice the
+// bound, which also absorbs the roundings of this comparison itself); otherwise, and whenever anything is non-finite, the
+// lane evaluates the reference's divisions in binary64.  About 1 test in 10^5 falls back.
+struct RayAux32 {
+  float invx, invy, invz, oix, oiy, oiz, slack;
+};
+__device__ __forceinline__ RayAux32 ray_aux32(const RayAux &a) {
+  RayAux32 r;
+  r.invx = (float)a.inv.x, r.invy = (float)a.inv.y, r.invz = (float)a.inv.z;
+  r.oix = (float)a.oi.x, r.oiy = (float)a.oi.y, r.oiz = (float)a.oi.z;
+  float m = fmaxf(fmaxf(fabsf(r.oix), fabsf(r.oiy)), fabsf(r.oiz));
+  r.slack = a.fast_ok ? m * 9.5367431640625e-07f : __int_as_float(0x7F800000);  // 16u, or +inf: never certain
+  return r;
+}
+__device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, float closest32, bool &certain) {
+  float t0x = fmaf(b[0], ra.invx, -ra.oix), t1x = fmaf(b[1], ra.invx, -ra.oix);
+  float t0y = fmaf(b[2], ra.invy, -ra.oiy), t1y = fmaf(b[3], ra.invy, -ra.oiy);
+  float t0z = fmaf(b[4], ra.invz, -ra.oiz), t1z = fmaf(b[5], ra.invz, -ra.oiz);
+  float tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
+  float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), closest32);
+  float diff = tmax - tmin;
+  float thresh = fmaf(tmin + fabsf(tmax), 4.76837158203125e-07f, ra.slack);  // 8u(|tmin|+|tmax|) + slack
+  certain = fabsf(diff) > thresh;                                            // false also for NaN / inf arithmetic
+  return diff > 0.0f;
+}
+
 // LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2
 template <int NT, int LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
@@ -148,8 +178,15 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
       if ((i & 3u) == 3u) {  // {w_hit, w_miss, a, b}: successor indices -> LDS byte offsets
         v.x = (v.x & 0xE0000000u) | ((v.x & 0x1FFFFFFFu) << 6);
         v.y = (v.y & 0xE0000000u) | ((v.y & 0x1FFFFFFFu) << 6);
+        l[i] = v;
       }
-      l[i] = v;
+    }
+    // the box, re-stored as six floats in the first 24 bytes of the op (the binary64 box stays in HBM for the exact path)
+    for (uint32_t i = tid; i < P.n_ops; i += NT) {
+      const double *bx = P.lops[i].box;
+      float *f = (float *)(s_ops + i);
+#pragma unroll
+      for (int k = 0; k < 6; k++) f[k] = (float)bx[k];
     }
     if (LDS_SCENE == 1) {
       g = (const uint4 *)P.spheres;
@@ -176,6 +213,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   D3 sum = d3(0.0, 0.0, 0.0);
   D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), thr = d3(1.0, 1.0, 1.0);
   RayAux ra = ray_aux(o, d);
+  RayAux32 ra32 = ray_aux32(ra);
   double time = 0.0, closest = INF;
   uint32_t pc = 0, hit_prim = NONE, depth = 0;
   uint32_t c_rays = 0, c_flag = 0;
@@ -220,10 +258,16 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           // one LDS round trip: the whole 64-B linked op {box, w_hit, w_miss}; every op stepped here is a box op,
           // the successor words already carry the state the lane enters there (rl_render.hip link_ops)
           const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
-          double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
           uint32_t w_hit = op.code, w_miss = op.skip;
-          bool certain;
-          bool hitb = aabb_fast(bx, ra, closest, certain, P.k8u);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+          bool certain, hitb;
+          if (LDS_SCENE) {
+            const float *fb = (const float *)&op;
+            float bx[6] = {fb[0], fb[1], fb[2], fb[3], fb[4], fb[5]};
+            hitb = aabb_fast32(bx, ra32, (float)closest, certain);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+          } else {
+            double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+            hitb = aabb_fast(bx, ra, closest, certain, P.k8u);
+          }
           if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
           if (STATS) c_nodes++;
           uint32_t w = hitb ? w_hit : w_miss;
@@ -322,6 +366,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             pix_rays++;
             ra = ray_aux(o, d);
             if (!ra.fast_ok) ra.slack = INF;
+            ra32 = ray_aux32(ra);
             pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
             state = entry0 >> 29;
           }
@@ -413,6 +458,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           d = nd;
           ra = ray_aux(o, d);
           if (!ra.fast_ok) ra.slack = INF;
+          ra32 = ray_aux32(ra);
           pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
           state = entry0 >> 29;
         }
