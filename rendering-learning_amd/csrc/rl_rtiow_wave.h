@@ -143,7 +143,11 @@ __device__ __forceinline__ RayAux32 ray_aux32(const RayAux &a) {
   r.invx = (float)a.inv.x, r.invy = (float)a.inv.y, r.invz = (float)a.inv.z;
   r.oix = (float)a.oi.x, r.oiy = (float)a.oi.y, r.oiz = (float)a.oi.z;
   float m = fmaxf(fmaxf(fabsf(r.oix), fabsf(r.oiy)), fabsf(r.oiz));
-  r.slack = a.fast_ok ? m * 9.5367431640625e-07f : __int_as_float(0x7F800000);  // 16u, or +inf: never certain
+  // the bound above needs every product and sum to stay a NORMAL binary32 number: 1/d within [1e-30, 1e30] and |o/d| <= 1e30
+  // (a zero, denormal-scale or huge direction component, or a far-away origin, makes the lane use the exact path always)
+  float imin = fminf(fminf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz)), imax = fmaxf(fmaxf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz));
+  bool ok = a.fast_ok && imin >= 1e-30f && imax <= 1e30f && m <= 1e30f;  // NaN compares false
+  r.slack = ok ? m * 9.5367431640625e-07f : __int_as_float(0x7F800000);  // 16u, or +inf: never certain
   return r;
 }
 __device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, float closest32, bool &certain) {

@@ -115,6 +115,25 @@ def test_rays_parallel_to_box_faces_and_huge_scenes_take_the_exact_path(rl, orac
     _check(rl, oracle, world, p, allow_degenerate=True)
 
 
+def test_directions_and_origins_outside_the_binary32_range_take_the_exact_path(rl, oracle):
+    """The headline kernel filters AABB tests in binary32: a direction component of 1e-50 (1/d overflows a float), one of
+    1e45, or an origin 1e35 away must switch the lane to the reference's binary64 divisions, not to inf / NaN arithmetic."""
+    api = rl.api
+    tex, mats = _materials(rl)
+    rng = np.random.default_rng(3)
+    sph = np.zeros(40, dtype=api.SPHERE)
+    sph["center0"] = rng.uniform(-3, 3, (40, 3)) + (0, 0, -6)
+    sph["radius"] = rng.uniform(0.2, 0.9, 40)
+    sph["material"] = rng.integers(0, 3, 40)
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    # vfov tiny + huge focus distance: pixel_du / pixel_dv of ~1e-50 (tiny x / y direction components after lookfrom - pixel)
+    for kw in (dict(vfov=1e-48, lookfrom=(0.0, 0.0, 2.0), lookat=(0.0, 0.0, -6.0)),
+               dict(vfov=40.0, lookfrom=(0.0, 0.0, 1e35), lookat=(0.0, 0.0, -6.0)),
+               dict(vfov=40.0, lookfrom=(1e-45, 2e-45, 2.0), lookat=(0.0, 0.0, -6.0))):
+        p = rl.CameraParams(aspect_ratio=1.0, image_width=24, samples_per_pixel=2, max_depth=5, defocus_angle=0.0, **kw)
+        _check(rl, oracle, world, p, allow_degenerate=True)
+
+
 def test_rtc_empty_world_no_lights_and_single_pixel(rl, oracle):
     api = rl.api
     empty = rl.RtcWorld.from_arrays(np.zeros(0, dtype=api.RTC_TRIANGLE), np.zeros(0, dtype=api.RTC_MATERIAL), np.zeros(0, dtype=api.HREF),
