@@ -40,6 +40,12 @@ struct alignas(16) DevOp {  // 64 B
 };
 static_assert(sizeof(DevOp) == 64, "DevOp must be 64 B");
 
+struct alignas(16) CompactOp {  // 32 B: the wave kernel's LDS form of a box / guard op
+  float box[6];            // binary32 (round to nearest) box; NaN = never certain
+  uint32_t w_hit, w_miss;  // successor words: state << 29 | op index
+};
+static_assert(sizeof(CompactOp) == 32, "CompactOp must be 32 B");
+
 struct alignas(16) DevSphere {  // 64 B
   double c0[3];
   double dc[3];   // center1 - center0 (sphere.rs:27: p2 - p1), 0 when stationary

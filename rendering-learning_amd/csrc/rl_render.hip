@@ -90,6 +90,9 @@ struct rl_scene {
   DevOp *d_lops = nullptr;  // linked form of the ops for the wave kernel (sphere-only scenes)
   DevMaterial *d_sphere_flat = nullptr;  // per-sphere flattened materials for the wave kernel
   uint32_t entry0 = 0;
+  CompactOp *d_cops = nullptr;  // guarded 32-byte ops (wave kernel, LDS_SCENE = 3)
+  uint32_t *d_movbits = nullptr;
+  uint32_t n_cops = 0, centry0 = 0;
   DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
   DevPlanar *d_planars = nullptr;
@@ -152,7 +155,7 @@ int rl_init(int device) {
   if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   g_ready = true;
@@ -179,7 +182,7 @@ int rl_device_info(char *name, int cap) {
 
 void rl_scene_destroy(rl_scene *s) {
   if (!s) return;
-  hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
+  hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_cops), hipFree(s->d_movbits), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
@@ -202,9 +205,36 @@ static int scene_common(rl_scene *s) {
 // become {w_hit, w_miss} = (state the lane enters there) << 29 | (op index): BOX hit -> op i+1, BOX_SPH hit ->
 // the same op in LEAF, miss / leaf done -> op `skip`; a target that is OP_END means "SHADE", a bare OP_SPHERE
 // "LEAF".  Boxes that are not BOX_FINITE are stored as NaN so the filtered test can never call them certain.
-static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out) {
+//
+// guards != nullptr: every sphere additionally gets a GUARD op at index n_ops + sphere — the sphere's own bounding box
+// (sphere.rs:77-88), tested by the same filter in a TRAV step but only ever used to REJECT (not one of the reference's
+// tests, not counted) — and a guard leads to a LEAF visit of that ONE sphere:
+//     leaf box hit -> guard(a) -> [LEAF a] -> guard(b) -> [LEAF b] -> the leaf's skip target.
+// A ray that certainly misses a sphere's box certainly misses the sphere, so the expensive binary64 Sphere::hit is skipped
+// for it (65 % of the leaf visits of BASELINE configs[1] end without a new closest hit).  Needs every sphere to be
+// referenced exactly once (*guards_ok = false otherwise).
+static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out, const rl_rtiow_scene_desc *guards = nullptr, bool *guards_ok = nullptr) {
+  const uint32_t n0 = (uint32_t)ops.size();
+  if (guards) {
+    std::vector<uint8_t> seen(guards->n_spheres, 0);
+    bool ok = true;
+    for (uint32_t i = 0; i < n0 && ok; i++) {
+      uint32_t kind = ops[i].code & 0xFFu;
+      if (kind != OP_BOX_SPH && kind != OP_SPHERE) continue;
+      for (uint32_t payload : {ops[i].a, ops[i].b}) {
+        if (payload == NONE) continue;
+        uint32_t sidx = payload & SPH_INDEX;
+        if (seen[sidx]) ok = false;
+        seen[sidx] = 1;
+      }
+    }
+    if (guards_ok) *guards_ok = ok;
+    if (!ok) guards = nullptr;
+  }
+  auto guard_of = [&](uint32_t payload) { return n0 + (payload & SPH_INDEX); };
   auto entry = [&](uint32_t t) -> uint32_t {
     uint32_t kind = ops[t].code & 0xFFu;
+    if (guards && kind == OP_SPHERE) return (ST_TRAV << 29) | guard_of(ops[t].a);
     uint32_t st = kind == OP_END ? ST_SHADE : (kind == OP_SPHERE ? ST_LEAF : ST_TRAV);
     return (st << 29) | t;
   };
@@ -216,10 +246,46 @@ static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out)
     DevOp &L = out[i];
     L.skip = entry(ops[i].skip);
     if (kind == OP_BOX) L.code = entry((uint32_t)i + 1u);
-    else if (kind == OP_BOX_SPH) L.code = (ST_LEAF << 29) | (uint32_t)i;
+    else if (kind == OP_BOX_SPH) L.code = guards ? ((ST_TRAV << 29) | guard_of(ops[i].a)) : ((ST_LEAF << 29) | (uint32_t)i);
     else L.code = L.skip;  // OP_SPHERE: never stepped in TRAV
     if ((kind == OP_BOX || kind == OP_BOX_SPH) && !(ops[i].code & BOX_FINITE))
       for (double &b : L.box) b = qnan;
+  }
+  if (guards) {
+    DevOp none{};
+    for (double &b : none.box) b = qnan;
+    none.code = none.skip = ST_SHADE << 29;
+    none.a = none.b = NONE;
+    out.resize((size_t)n0 + guards->n_spheres, none);  // spheres outside the tree keep a harmless record
+    for (uint32_t i = 0; i < n0; i++) {
+      uint32_t kind = ops[i].code & 0xFFu;
+      if (kind != OP_BOX_SPH && kind != OP_SPHERE) continue;
+      const uint32_t after = entry(ops[i].skip);
+      for (int k = 0; k < 2; k++) {
+        uint32_t payload = k == 0 ? ops[i].a : ops[i].b;
+        if (payload == NONE) continue;
+        const rl_sphere &sp = guards->spheres[payload & SPH_INDEX];
+        DevOp G{};
+        double r = std::fabs(sp.radius);
+        for (int ax = 0; ax < 3; ax++) {
+          double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
+          double lo = std::fmin(c0, c1) - r, hi = std::fmax(c0, c1) + r;
+          double pad = 1e-9 * (std::fabs(lo) + std::fabs(hi) + r);  // this box only ever rejects: keep it comfortably outside the sphere
+          G.box[2 * ax] = lo - pad, G.box[2 * ax + 1] = hi + pad;
+        }
+        for (int ax = 0; ax < 6; ax++)
+          if (!(std::fabs(G.box[ax]) <= 1e30)) {  // NaN / inf / huge: never certain, i.e. always test the sphere
+            for (double &b : G.box) b = qnan;
+            break;
+          }
+        const uint32_t self = guard_of(payload);
+        G.code = (ST_LEAF << 29) | self;  // box "hit" (or not certain): test the sphere
+        const bool more = k == 0 && ops[i].b != NONE;
+        G.skip = more ? ((ST_TRAV << 29) | guard_of(ops[i].b)) : after;  // then the leaf's other sphere, then on
+        G.a = payload, G.b = NONE;
+        out[self] = G;
+      }
+    }
   }
   return ops.empty() ? (uint32_t)(ST_SHADE << 29) : entry(0);
 }
@@ -280,6 +346,25 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
     if (upload(lops, &s->d_lops) != RL_OK || upload(flat, &s->d_sphere_flat) != RL_OK) {
       rl_scene_destroy(s);
       return nullptr;
+    }
+    // compact guarded form (32-byte ops: binary32 box + the two successor words) for the 4-waves-per-SIMD layout
+    std::vector<DevOp> gops;
+    bool gok = false;
+    uint32_t gentry = link_ops(s->rt.ops, gops, desc, &gok);
+    if (gok && gops.size() < (1u << 24)) {
+      std::vector<CompactOp> cops(gops.size());
+      for (size_t i = 0; i < gops.size(); i++) {
+        for (int k = 0; k < 6; k++) cops[i].box[k] = (float)gops[i].box[k];
+        cops[i].w_hit = gops[i].code, cops[i].w_miss = gops[i].skip;
+      }
+      std::vector<uint32_t> movbits((s->rt.spheres.size() + 31) / 32 + 1, 0u);
+      for (size_t i = 0; i < s->rt.spheres.size(); i++)
+        if (desc->spheres[i].moving) movbits[i >> 5] |= 1u << (i & 31);
+      if (upload(cops, &s->d_cops) != RL_OK || upload(movbits, &s->d_movbits) != RL_OK) {
+        rl_scene_destroy(s);
+        return nullptr;
+      }
+      s->n_cops = (uint32_t)cops.size(), s->centry0 = gentry;
     }
   }
   return s;
@@ -398,6 +483,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins;
   P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
   P.lops = scene->d_lops, P.entry0 = scene->entry0, P.sphere_flat = scene->d_sphere_flat;
+  P.cops = scene->d_cops, P.n_cops = scene->n_cops, P.centry0 = scene->centry0, P.movbits = scene->d_movbits;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;
@@ -444,6 +530,9 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images || scene->rt.has_noise;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
+  const size_t compact_bytes = ((size_t)scene->n_cops * sizeof(CompactOp) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const bool fits_compact = scene->n_cops != 0 && (size_t)16 * 1024 * sizeof(unsigned long long) + compact_bytes <= g_lds_max;
+  if (variant == 1027 && (general || !fits_compact)) variant = 0;
   if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
   if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS
@@ -452,7 +541,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     // else 3 (or 2) waves per SIMD with the whole scene in LDS; else 4 waves per SIMD reading everything from HBM / L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
-    variant = fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
+    variant = fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
   auto launch_variant = [&]() -> int {
     int rc;
@@ -499,6 +588,10 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp);
       rc = want_stats ? launch(rtiow_wave_kernel<NT, 2, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 2, false>, NT, rb, false);
+    } else if (variant == 1027) {  // 4 waves per SIMD: rings + compact guarded ops in LDS, spheres read from L2
+      constexpr int NT = 1024;
+      size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + compact_bytes;
+      rc = want_stats ? launch(rtiow_wave_kernel<NT, 3, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 3, false>, NT, rb, false);
     } else if (variant == 768) RL_LAUNCH_WAVE(768)
     else if (variant == 1024) RL_LAUNCH_WAVE(1024)
     else if (variant == 256) RL_LAUNCH_WAVE(256)

@@ -28,6 +28,9 @@ struct RtiowParams {
   const DevMaterial *sphere_flat;  // wave kernel: per-sphere flattened material (see flatten_sphere_materials)
   const DevOp *lops;  // wave kernel: ops with {code, skip} replaced by linked successor words (state << 29 | op index), see link_ops
   uint32_t entry0;    // linked word of op 0: where (and in which state) a new ray starts
+  const CompactOp *cops;    // wave kernel LDS_SCENE = 3: guarded compact ops (n_ops originals + one guard per sphere)
+  const uint32_t *movbits;  // ... one bit per sphere: Center::Moving
+  uint32_t n_cops, centry0;
   rl_rtiow_camera cam;
   uint32_t key[8];
   uint64_t first_sample;

@@ -162,17 +162,38 @@ __device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, 
   return diff > 0.0f;
 }
 
-// LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2
+// LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2,
+// 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2
 template <int NT, int LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
-  const size_t scene_lds = LDS_SCENE ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0)) : 0;
+  const size_t bits_words = ((size_t)P.n_spheres + 31) / 32 + 1;
+  const size_t scene_lds = LDS_SCENE == 3 ? (((size_t)P.n_cops * sizeof(CompactOp) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
+                           : LDS_SCENE  ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0))
+                                        : 0;
   unsigned long long *s_rng = (unsigned long long *)(smem + scene_lds);  // [16][NT]
   const unsigned char *opbase = (const unsigned char *)P.lops;  // pc is an index (HBM) or a byte offset (LDS) into this
   const DevSphere *spheres = P.spheres;
-  if (LDS_SCENE) {
+  const uint32_t *s_bits = nullptr;  // LDS_SCENE == 3: one bit per sphere (Center::Moving)
+  if (LDS_SCENE == 3) {
+    const uint4 *g = (const uint4 *)P.cops;
+    uint4 *l = (uint4 *)smem;
+    for (uint32_t i = tid; i < P.n_cops * 2u; i += NT) {
+      uint4 v = g[i];
+      if (i & 1u) {  // {box[4], box[5], w_hit, w_miss}: successor indices -> LDS byte offsets
+        v.z = (v.z & 0xE0000000u) | ((v.z & 0x1FFFFFFFu) << 5);
+        v.w = (v.w & 0xE0000000u) | ((v.w & 0x1FFFFFFFu) << 5);
+      }
+      l[i] = v;
+    }
+    uint32_t *bl = (uint32_t *)(smem + (size_t)P.n_cops * sizeof(CompactOp));
+    for (uint32_t i = tid; i < (uint32_t)bits_words; i += NT) bl[i] = P.movbits[i];
+    __syncthreads();
+    opbase = smem;
+    s_bits = bl;
+  } else if (LDS_SCENE) {
     DevOp *s_ops = (DevOp *)smem;
     DevSphere *s_sph = (DevSphere *)(s_ops + P.n_ops);
     const uint4 *g = (const uint4 *)P.lops;
@@ -201,7 +222,9 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     __syncthreads();
     opbase = smem;
   }
-  const uint32_t entry0 = LDS_SCENE ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6)) : P.entry0;
+  const uint32_t entry0 = LDS_SCENE == 3 ? ((P.centry0 & 0xE0000000u) | ((P.centry0 & 0x1FFFFFFFu) << 5))
+                          : LDS_SCENE  ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6))
+                                       : P.entry0;
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
   const uint32_t s_begin = P.sample_begin, spp = P.sample_end;  // this launch renders samples [s_begin, spp) of every pixel
@@ -261,19 +284,31 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
         if (state == ST_TRAV) {
           // one LDS round trip: the whole 64-B linked op {box, w_hit, w_miss}; every op stepped here is a box op,
           // the successor words already carry the state the lane enters there (rl_render.hip link_ops)
-          const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
-          uint32_t w_hit = op.code, w_miss = op.skip;
+          uint32_t w_hit, w_miss;
           bool certain, hitb;
-          if (LDS_SCENE) {
-            const float *fb = (const float *)&op;
-            float bx[6] = {fb[0], fb[1], fb[2], fb[3], fb[4], fb[5]};
-            hitb = aabb_fast32(bx, ra32, (float)closest, certain);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+          if (LDS_SCENE == 3) {  // 32-byte op: binary32 box + the two successor words
+            const CompactOp &op = *(const CompactOp *)(opbase + pc);
+            float bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+            w_hit = op.w_hit, w_miss = op.w_miss;
+            hitb = aabb_fast32(bx, ra32, (float)closest, certain);
+            const uint32_t op_index = pc >> 5;
+            const bool guard = op_index >= P.n_ops;  // a sphere's own box: only ever REJECTS; not one of the reference's tests
+            if (!certain) hitb = guard ? true : aabb_hit(P.ops[op_index].box, o, d, 1e-10, closest);  // rare: exact divisions
+            if (STATS) c_nodes += guard ? 0u : 1u, c_sph += guard ? 1u : 0u;  // the guarded Sphere::hit counts, skipped or not
           } else {
-            double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
-            hitb = aabb_fast(bx, ra, closest, certain, P.k8u);
+            const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
+            w_hit = op.code, w_miss = op.skip;
+            if (LDS_SCENE) {
+              const float *fb = (const float *)&op;
+              float bx[6] = {fb[0], fb[1], fb[2], fb[3], fb[4], fb[5]};
+              hitb = aabb_fast32(bx, ra32, (float)closest, certain);  // non-finite boxes are NaN here, !fast_ok rays have slack = inf: never certain
+            } else {
+              double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+              hitb = aabb_fast(bx, ra, closest, certain, P.k8u);
+            }
+            if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
+            if (STATS) c_nodes++;
           }
-          if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
-          if (STATS) c_nodes++;
           uint32_t w = hitb ? w_hit : w_miss;
           pc = w & 0x1FFFFFFFu;
           state = w >> 29;
@@ -282,12 +317,19 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
       }
     } else if (pick == ST_LEAF) {
       if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
-        const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
-        uint32_t a = op.a, b = op.b, w = op.skip;
+        uint32_t a, b, w;
+        if (LDS_SCENE == 3) {  // a guard op: the ONE sphere it stands for (index = op index - n_ops), counted at the guard step
+          const CompactOp &op = *(const CompactOp *)(opbase + pc);
+          const uint32_t sidx = (pc >> 5) - P.n_ops;
+          a = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u), b = NONE, w = op.w_miss;
+        } else {
+          const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
+          a = op.a, b = op.b, w = op.skip;
+          if (STATS) c_sph++;
+        }
         Hit h{closest, hit_prim};
-        if (STATS) c_sph++;
         if (sphere_hit(spheres[a & SPH_INDEX], a, o, d, time, 1e-10, h)) c_flag++;
-        if (b != NONE) {
+        if (LDS_SCENE != 3 && b != NONE) {
           if (STATS) c_sph++;
           if (sphere_hit(spheres[b & SPH_INDEX], b, o, d, time, 1e-10, h)) c_flag++;
         }
