@@ -496,7 +496,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   P.out = (double *)d_out;
   P.k8u = 8.8817841970012523e-16;
-  P.tune[0] = 16, P.tune[1] = 6, P.tune[2] = 24, P.tune[3] = 40;
+  P.tune[0] = 24, P.tune[1] = 6, P.tune[2] = 24, P.tune[3] = 40;
   if (const char *t = std::getenv("RL_TUNE")) {  // "iters,floor16[,refill_batch,refill_fill]" (A/B only)
     unsigned a = 16, b = 12, c = 24, d = 40;
     int nf = std::sscanf(t, "%u,%u,%u,%u", &a, &b, &c, &d);
