@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     if (pick == ST_TRAV) {
       // several steps per scheduling decision while the population stays near its starting size
       int floor_n = (best * (int)P.tune[1]) >> 4;
-      for (int it = 0; it < (int)P.tune[0]; it++) {
+      auto trav_step = [&]() {
         if (STATS) {
           int np = __popcll(__ballot(state == ST_TRAV));
           sc_exec[ST_TRAV]++, sc_pop[ST_TRAV] += (unsigned)np;
@@ -313,6 +313,10 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           pc = w & 0x1FFFFFFFu;
           state = w >> 29;
         }
+      };
+      for (int it = 0; it < (int)P.tune[0]; it += 2) {  // two steps per population check
+        trav_step();
+        trav_step();
         if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
       }
     } else if (pick == ST_LEAF) {
