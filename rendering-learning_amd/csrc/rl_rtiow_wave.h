@@ -164,6 +164,8 @@ __device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, 
 
 // LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2,
 // 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2
+typedef __attribute__((address_space(3))) CompactOp LdsCompactOp;
+
 template <int NT, int LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,14 +179,15 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   const unsigned char *opbase = (const unsigned char *)P.lops;  // pc is an index (HBM) or a byte offset (LDS) into this
   const DevSphere *spheres = P.spheres;
   const uint32_t *s_bits = nullptr;  // LDS_SCENE == 3: one bit per sphere (Center::Moving)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;  // the dynamic LDS segment's own address (low half of the flat address)
   if (LDS_SCENE == 3) {
     const uint4 *g = (const uint4 *)P.cops;
     uint4 *l = (uint4 *)smem;
     for (uint32_t i = tid; i < P.n_cops * 2u; i += NT) {
       uint4 v = g[i];
-      if (i & 1u) {  // {box[4], box[5], w_hit, w_miss}: successor indices -> LDS byte offsets
-        v.z = (v.z & 0xE0000000u) | ((v.z & 0x1FFFFFFFu) << 5);
-        v.w = (v.w & 0xE0000000u) | ((v.w & 0x1FFFFFFFu) << 5);
+      if (i & 1u) {  // {box[4], box[5], w_hit, w_miss}: successor indices -> absolute LDS addresses (no add per step)
+        v.z = (v.z & 0xE0000000u) | (((v.z & 0x1FFFFFFFu) << 5) + lds_base);
+        v.w = (v.w & 0xE0000000u) | (((v.w & 0x1FFFFFFFu) << 5) + lds_base);
       }
       l[i] = v;
     }
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     __syncthreads();
     opbase = smem;
   }
-  const uint32_t entry0 = LDS_SCENE == 3 ? ((P.centry0 & 0xE0000000u) | ((P.centry0 & 0x1FFFFFFFu) << 5))
+  const uint32_t entry0 = LDS_SCENE == 3 ? ((P.centry0 & 0xE0000000u) | (((P.centry0 & 0x1FFFFFFFu) << 5) + lds_base))
                           : LDS_SCENE  ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6))
                                        : P.entry0;
   const rl_rtiow_camera &cam = P.cam;
@@ -287,11 +290,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           uint32_t w_hit, w_miss;
           bool certain, hitb;
           if (LDS_SCENE == 3) {  // 32-byte op: binary32 box + the two successor words
-            const CompactOp &op = *(const CompactOp *)(opbase + pc);
+            const LdsCompactOp &op = *(const LdsCompactOp *)(size_t)pc;
             float bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
             w_hit = op.w_hit, w_miss = op.w_miss;
             hitb = aabb_fast32(bx, ra32, (float)closest, certain);
-            const uint32_t op_index = pc >> 5;
+            const uint32_t op_index = (pc - lds_base) >> 5;
             const bool guard = op_index >= P.n_ops;  // a sphere's own box: only ever REJECTS; not one of the reference's tests
             if (!certain) hitb = guard ? true : aabb_hit(P.ops[op_index].box, o, d, 1e-10, closest);  // rare: exact divisions
             if (STATS) c_nodes += guard ? 0u : 1u, c_sph += guard ? 1u : 0u;  // the guarded Sphere::hit counts, skipped or not
@@ -323,8 +326,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
       if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
         uint32_t a, b, w;
         if (LDS_SCENE == 3) {  // a guard op: the ONE sphere it stands for (index = op index - n_ops), counted at the guard step
-          const CompactOp &op = *(const CompactOp *)(opbase + pc);
-          const uint32_t sidx = (pc >> 5) - P.n_ops;
+          const LdsCompactOp &op = *(const LdsCompactOp *)(size_t)pc;
+          const uint32_t sidx = ((pc - lds_base) >> 5) - P.n_ops;
           a = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u), b = NONE, w = op.w_miss;
         } else {
           const DevOp &op = *(const DevOp *)(LDS_SCENE ? opbase + pc : opbase + (size_t)pc * sizeof(DevOp));
