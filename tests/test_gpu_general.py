@@ -140,6 +140,11 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
         rl.api.set_rtiow_variant(7)  # two pixel contexts per lane, one-block ChaCha rings, restartable draws
         st2 = {}
         f = cam.render(world, stats=st2).data
+        others = []
+        for v in (1025, 1024, 512, 256):  # 1024 lanes with 64-byte ops (no guards); every lane count of the 3-waves layout; 1024 = scene in HBM
+            rl.api.set_rtiow_variant(v)
+            sv = {}
+            others.append((v, cam.render(world, stats=sv).data, sv))
         rl.api.set_rtiow_variant(768)
         st0 = {}
         cam.render(world, stats=st0)
@@ -148,6 +153,10 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
     assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) and np.array_equal(a, e) and np.array_equal(a, f)
     for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
         assert st[k] == st0[k] and st2[k] == st0[k], k
+    for v, img, sv in others:
+        assert np.array_equal(a, img), v
+        for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
+            assert sv[k] == st0[k], (v, k)
 
 
 def test_stress_scene_cfg5_reduced(rl, oracle, golden):
