@@ -120,6 +120,13 @@ struct alignas(16) DevTri {  // 160 B
 };
 static_assert(sizeof(DevTri) == 160, "DevTri must be 160 B");
 
+struct alignas(16) RtcGuard {  // 32 B: node of the reject-only binary32 box tree over one ROP_TRIS range (rl_render.hip build_rtc_guards)
+  float box[6];   // x.min,x.max,y.min,y.max,z.min,z.max of the triangles below, padded outwards
+  uint32_t skip;  // next node when this box is certainly missed (inner: hit -> next node in the array)
+  uint32_t tri;   // leaf: the triangle to test; NONE for inner nodes
+};
+static_assert(sizeof(RtcGuard) == 32, "RtcGuard must be 32 B");
+
 struct RtcProgram {
   std::vector<DevOp> ops;
   std::vector<DevTri> tris;

@@ -112,6 +112,8 @@ struct rl_scene {
   rl_rtc_shape *d_shapes = nullptr;
   rl_rtc_csg *d_csgs = nullptr;
   rl_rtc_pattern *d_patterns = nullptr;
+  RtcGuard *d_guards = nullptr;  // reject-only box trees over the ROP_TRIS ranges (fast triangle kernel)
+  uint32_t n_guards = 0;
   // per-scene scratch: [0] work counter (u32), [8..] 8 x u64 stats
   unsigned char *d_scratch = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -186,7 +188,7 @@ void rl_scene_destroy(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards);
   hipFree(s->wf_pix), hipFree(s->wf_ray), hipFree(s->wf_hit), hipFree(s->wf_qtrav), hipFree(s->wf_qshade), hipFree(s->wf_qgen), hipFree(s->wf_ctl), hipFree(s->wf_class);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
@@ -738,6 +740,57 @@ int rl_rtiow_render(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t 
 }
 
 // ------------------------------------------------------------------ RTC
+// Reject-only acceleration for the triangle Groups of the RTC path.  The reference's Group (group.rs) intersects every child
+// for every ray; for each ROP_TRIS range of >= 8 triangles a binary tree over the triangles IN INDEX ORDER is built here (node =
+// index range, box = padded union of the triangles' bounding boxes, stored as floats; leaves = single triangles; nodes in
+// depth-first order so that a left-to-right walk meets the triangles in the reference's order) and the op's `skip` field gets
+// root + 1.  The kernel skips a triangle only when its box is CERTAINLY missed (guard_reject32), so every intersection the
+// reference would keep is still found, in the same order.
+static void build_rtc_guards(RtcProgram &rc, std::vector<RtcGuard> &guards) {
+  struct Builder {
+    const std::vector<DevTri> &tris;
+    std::vector<RtcGuard> &out;
+    void box_of(uint32_t l, uint32_t r, float *b) const {
+      double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (uint32_t i = l; i < r; i++) {
+        const DevTri &t = tris[i];
+        for (int ax = 0; ax < 3; ax++) {
+          const double v[3] = {t.p1[ax], t.p1[ax] + t.e1[ax], t.p1[ax] + t.e2[ax]};
+          for (double x : v) mn[ax] = std::fmin(mn[ax], x), mx[ax] = std::fmax(mx[ax], x);
+        }
+      }
+      bool bad = false;
+      for (int ax = 0; ax < 3; ax++) {
+        double pad = 1e-6 * (std::fabs(mn[ax]) + std::fabs(mx[ax]) + (mx[ax] - mn[ax])) + 1e-30;  // the box only ever rejects: keep it outside the triangles
+        b[2 * ax] = (float)(mn[ax] - pad), b[2 * ax + 1] = (float)(mx[ax] + pad);
+        bad |= !(std::fabs(mn[ax]) <= 1e30 && std::fabs(mx[ax]) <= 1e30);
+      }
+      if (bad)
+        for (int k = 0; k < 6; k++) b[k] = NAN;  // never certainly missed
+    }
+    void build(uint32_t l, uint32_t r) {
+      const uint32_t idx = (uint32_t)out.size();
+      out.push_back(RtcGuard{});
+      RtcGuard nd{};
+      box_of(l, r, nd.box);
+      if (r - l == 1) nd.tri = l, nd.skip = idx + 1;
+      else {
+        const uint32_t m = l + (r - l) / 2;
+        build(l, m);
+        build(m, r);
+        nd.tri = NONE, nd.skip = (uint32_t)out.size();
+      }
+      out[idx] = nd;
+    }
+  };
+  Builder b{rc.tris, guards};
+  for (DevOp &op : rc.ops)
+    if (op.code == ROP_TRIS && op.b >= 8) {
+      op.skip = (uint32_t)guards.size() + 1u;
+      b.build(op.a, op.a + op.b);
+    }
+}
+
 rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
   if (!g_ready) {
     set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
@@ -761,6 +814,13 @@ rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
     return nullptr;
   }
   int rc = RL_OK;
+  std::vector<RtcGuard> guards;
+  if (!s->rc.needs_full) build_rtc_guards(s->rc, guards);
+  s->n_guards = (uint32_t)guards.size();
+  if (!guards.empty() && upload(guards, &s->d_guards) != RL_OK) {
+    rl_scene_destroy(s);
+    return nullptr;
+  }
   if ((rc = upload(s->rc.ops, &s->d_ops)) || (rc = upload(s->rc.tris, &s->d_tris)) || (rc = upload(s->rc.xforms, &s->d_xforms)) ||
       (rc = upload(s->rc.materials, &s->d_rmaterials)) || (rc = upload(s->rc.lights, &s->d_lights)) || (rc = upload(s->rc.shapes, &s->d_shapes)) ||
       (rc = upload(s->rc.csgs, &s->d_csgs)) || (rc = upload(s->rc.patterns, &s->d_patterns)) || (rc = scene_common(s))) {
@@ -785,6 +845,7 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
   RtcParams P{};
   P.ops = scene->d_ops, P.tris = scene->d_tris, P.xforms = scene->d_xforms, P.materials = scene->d_rmaterials, P.lights = scene->d_lights;
   P.n_ops = (uint32_t)scene->rc.ops.size(), P.n_tris = (uint32_t)scene->rc.tris.size();
+  P.guards = scene->n_guards ? scene->d_guards : nullptr, P.n_guards = scene->n_guards;
   P.n_xforms = (uint32_t)scene->rc.xforms.size(), P.n_lights = (uint32_t)scene->rc.lights.size();
   P.cam = *cam;
   P.aa = aa;
@@ -794,7 +855,7 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   constexpr int NT = 256;
-  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_tris * sizeof(DevTri);
+  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_tris * sizeof(DevTri) + (size_t)P.n_guards * sizeof(RtcGuard);
   bool lds_scene = scene_bytes <= 65536;
   size_t lds = lds_scene ? scene_bytes : 0;
   uint64_t total = (uint64_t)W * nrows;

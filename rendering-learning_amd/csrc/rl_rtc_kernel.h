@@ -21,6 +21,8 @@ struct RtcParams {
   const rl_rtc_transformed *xforms;
   const rl_rtc_material *materials;
   const rl_rtc_light *lights;
+  const RtcGuard *guards;  // reject-only box trees of the ROP_TRIS ops (op.skip = root + 1), or null
+  uint32_t n_guards;
   uint32_t n_ops, n_tris, n_xforms, n_lights;
   rl_rtc_camera cam;
   uint32_t aa;
@@ -79,11 +81,40 @@ struct RtcHit {
   D3 normal;
 };
 
+// ---- reject-only binary32 box test for the guard trees (same error analysis as aabb_fast32 in rl_rtiow_wave.h, u = 2^-24):
+// with inv32 = RN32(1/d), oi32 = RN32(o/d) each slab parameter is off by <= 3.2u|t| + 3.3u max|o/d|.  The Group of a mesh has
+// no acceleration structure in the reference (every ray tests every triangle, group.rs); a triangle whose padded box the ray
+// certainly misses inside the parameter range that can still matter ([0, best.t], shadow rays (0, distance)) certainly has no
+// intersection the reference would keep, so its (binary64) test is skipped — the counter still counts it.
+struct RtcAux32 {
+  float invx, invy, invz, oix, oiy, oiz, slack;
+};
+__device__ __forceinline__ RtcAux32 rtc_aux32(D3 o, D3 d) {
+  RtcAux32 r;
+  double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
+  r.invx = (float)ix, r.invy = (float)iy, r.invz = (float)iz;
+  r.oix = (float)(o.x * ix), r.oiy = (float)(o.y * iy), r.oiz = (float)(o.z * iz);
+  float m = fmaxf(fmaxf(fabsf(r.oix), fabsf(r.oiy)), fabsf(r.oiz));
+  float imin = fminf(fminf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz)), imax = fmaxf(fmaxf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz));
+  bool ok = imin >= 1e-30f && imax <= 1e30f && m <= 1e30f;                        // NaN compares false
+  r.slack = ok ? fmaf(m, 9.5367431640625e-07f, 1e-30f) : __int_as_float(0x7F800000);  // 16u max|oi|, or +inf: never reject
+  return r;
+}
+__device__ __forceinline__ bool guard_reject32(const float *b, const RtcAux32 &ra, float tbound) {
+  float t0x = fmaf(b[0], ra.invx, -ra.oix), t1x = fmaf(b[1], ra.invx, -ra.oix);
+  float t0y = fmaf(b[2], ra.invy, -ra.oiy), t1y = fmaf(b[3], ra.invy, -ra.oiy);
+  float t0z = fmaf(b[4], ra.invz, -ra.oiz), t1z = fmaf(b[5], ra.invz, -ra.oiz);
+  float tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 0.0f);
+  float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), tbound);
+  float thresh = fmaf(tmin + fabsf(tmax), 4.76837158203125e-07f, ra.slack);  // 8u(|tmin|+|tmax|) + slack
+  return (tmin - tmax) > thresh;                                            // false for NaN / inf arithmetic
+}
+
 // One pass over the program. SHADOW=false: closest hit (lowest t >= 0, later wins).
 // SHADOW=true: product of transparency over hits with 0 < t < distance (world.rs:104-126).
 template <bool SHADOW>
-__device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *ops, const DevTri *tris, D3 wo, D3 wd, double distance, RtcHit &best,
-                                               RtcCounters &cnt) {
+__device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *ops, const DevTri *tris, const RtcGuard *guards, D3 wo, D3 wd, double distance,
+                                               RtcHit &best, RtcCounters &cnt) {
   D3 o = wo, d = wd;
   double atten = 1.0;
   uint32_t pc = 0;
@@ -93,26 +124,25 @@ __device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *
     if (code == ROP_END) break;
     if (code == ROP_TRIS) {
       uint32_t first = op.a, count = op.b;
-      for (uint32_t k = 0; k < count; k++) {  // triangle.rs:63-101
-        const DevTri &t = tris[first + k];
-        cnt.tris++;
+      auto test_triangle = [&](uint32_t ti) {  // triangle.rs:63-101
+        const DevTri &t = tris[ti];
         D3 e1 = ld3(t.e1), e2 = ld3(t.e2);
         D3 dir_cross_e2 = cross(d, e2);
         double det = dot(e1, dir_cross_e2);
-        if (fabs(det) < 1e-8) continue;
+        if (fabs(det) < 1e-8) return;
         double f = 1.0 / det;
         D3 p1_to_origin = o - ld3(t.p1);
         double u = f * dot(p1_to_origin, dir_cross_e2);
-        if (!(0.0 <= u && u <= 1.0)) continue;
+        if (!(0.0 <= u && u <= 1.0)) return;
         D3 origin_cross_e1 = cross(p1_to_origin, e1);
         double v = f * dot(d, origin_cross_e1);
-        if (v < 0.0 || (u + v) > 1.0) continue;
+        if (v < 0.0 || (u + v) > 1.0) return;
         double tt = f * dot(e2, origin_cross_e1);
         if (SHADOW) {
           if (tt > 0.0 && tt < distance) atten = atten * P.materials[t.material].transparency;
         } else if (tt >= 0.0 && !(best.t < tt)) {  // intersect.rs:159-168: `lowest.t < i.t ? lowest : i`
           best.t = tt;
-          best.tri = first + k;
+          best.tri = ti;
           best.pc = pc;
           if (t.smooth) {
             D3 n = (ld3(t.n2) * u + ld3(t.n3) * v) + ld3(t.n1) * (1.0 - u - v);
@@ -124,6 +154,29 @@ __device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *
             best.normal = nn;
           } else
             best.normal = ld3(t.n1);
+        }
+      };
+      if (guards && op.skip != 0u) {  // walk the reject-only box tree; its leaves come in triangle order, so ties resolve as in the loop
+        cnt.tris += count;             // the reference tests every triangle of the group
+        const RtcAux32 ax = rtc_aux32(o, d);
+        uint32_t g = op.skip - 1u;
+        const uint32_t gend = guards[g].skip;
+        while (g < gend) {
+          const RtcGuard &nd = guards[g];
+          const float bx[6] = {nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5]};
+          const uint32_t nskip = nd.skip, ntri = nd.tri;
+          const float tbound = SHADOW ? (float)distance : (float)best.t;
+          if (guard_reject32(bx, ax, tbound)) g = nskip;
+          else if (ntri == NONE) g++;
+          else {
+            test_triangle(ntri);
+            g = nskip;
+          }
+        }
+      } else {
+        for (uint32_t k = 0; k < count; k++) {
+          cnt.tris++;
+          test_triangle(first + k);
         }
       }
       pc++;
@@ -193,6 +246,7 @@ __global__ void __launch_bounds__(NT) rtc_kernel(RtcParams P) {
   const int tid = threadIdx.x;
   const DevOp *ops = P.ops;
   const DevTri *tris = P.tris;
+  const RtcGuard *guards = P.guards;
   if (LDS_SCENE) {
     DevOp *s_ops = (DevOp *)smem;
     DevTri *s_tris = (DevTri *)(s_ops + P.n_ops);
@@ -202,6 +256,13 @@ __global__ void __launch_bounds__(NT) rtc_kernel(RtcParams P) {
     g = (const uint4 *)P.tris;
     l = (uint4 *)s_tris;
     for (uint32_t i = tid; i < P.n_tris * 10u; i += NT) l[i] = g[i];
+    if (guards) {
+      RtcGuard *s_guards = (RtcGuard *)(s_tris + P.n_tris);
+      g = (const uint4 *)P.guards;
+      l = (uint4 *)s_guards;
+      for (uint32_t i = tid; i < P.n_guards * 2u; i += NT) l[i] = g[i];
+      guards = s_guards;
+    }
     __syncthreads();
     ops = s_ops;
     tris = s_tris;
@@ -233,7 +294,7 @@ __global__ void __launch_bounds__(NT) rtc_kernel(RtcParams P) {
         // World::color_at -> color_at_internal (world.rs:89-102)
         cnt.rays++;
         RtcHit best{INF, NONE, 0u, d3(0.0, 0.0, 0.0)};
-        rtc_traverse<false>(P, ops, tris, origin, dir, 0.0, best, cnt);
+        rtc_traverse<false>(P, ops, tris, guards, origin, dir, 0.0, best, cnt);
         D3 c = ld3(P.void_color);
         if (best.tri != NONE && P.n_lights > 0) {
           // prepare_computations (intersect.rs:48-71)
@@ -261,7 +322,7 @@ __global__ void __launch_bounds__(NT) rtc_kernel(RtcParams P) {
             if (norm(v, sdir)) {
               cnt.rays++;
               RtcHit dummy{INF, NONE, 0u, d3(0.0, 0.0, 0.0)};
-              shadow_att = rtc_traverse<true>(P, ops, tris, over_point, sdir, distance, dummy, cnt);
+              shadow_att = rtc_traverse<true>(P, ops, tris, guards, over_point, sdir, distance, dummy, cnt);
             }
             // lighting (material.rs:54-90)
             D3 effective = object_color * intensity;
