@@ -55,7 +55,10 @@ int rl_device_info(char *name, int cap);
 typedef struct rl_scene rl_scene;
 void rl_scene_destroy(rl_scene *);
 
-/* per-render counters; every field is a sum over the pixels rendered by the call */
+/* per-render counters; every field is a sum over the pixels rendered by the call.  They count the calls the REFERENCE's
+ * algorithm makes on the same input (the oracle's counters are equal, which is how the tests prove that every branch went the
+ * same way): where the device proves with a conservative bounding-box test that a Sphere::hit / Triangle::intersect cannot
+ * produce an intersection the reference would keep and skips the arithmetic, the call is still counted. */
 typedef struct rl_stats {
   uint64_t rays;            /* RTIOW: ray_color calls with depth>0 (camera.rs:232). RTC: color_at + shadow rays */
   uint64_t node_tests;      /* AABB::hit calls (aabb.rs:123) / Bounded::test (bounded.rs:100) */
