@@ -159,3 +159,41 @@ def test_rtc_empty_world_no_lights_and_single_pixel(rl, oracle):
         assert np.abs(a - b).max() <= 1e-12
         for k in ("rays", "node_tests", "sphere_tests"):
             assert gs[k] == cs[k]
+
+
+def test_rtc_triangle_guard_tree_keeps_order_ties_and_axis_parallel_rays(rl, oracle):
+    """The fast RTC kernel walks a reject-only box tree over triangle ranges of >= 8 triangles.  Coincident triangles (ties in t:
+    the later one must win, its material shows), triangles lying in axis planes (flat boxes), rays parallel to an axis
+    (1/d = inf: the tree must never reject) and shadow rays all have to come out as in the reference's plain loop."""
+    api = rl.api
+    rng = np.random.default_rng(17)
+    n = 40
+    tri = np.zeros(n, dtype=api.RTC_TRIANGLE)
+    p1 = rng.uniform(-2, 2, (n, 3))
+    e1, e2 = rng.uniform(-1.5, 1.5, (n, 3)), rng.uniform(-1.5, 1.5, (n, 3))
+    p1[:8, 2], e1[:8, 2], e2[:8, 2] = 1.0, 0.0, 0.0           # eight triangles in the plane z = 1 (zero-thickness boxes)
+    p1[20:24], e1[20:24], e2[20:24] = p1[8:12], e1[8:12], e2[8:12]  # four exact duplicates later in the list
+    tri["p1"], tri["e1"], tri["e2"] = p1, e1, e2
+    nrm = np.cross(e2, e1)
+    tri["n1"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    tri["material"] = np.arange(n) % 4
+    mats = np.zeros(4, dtype=api.RTC_MATERIAL)
+    mats["color"] = [(1, 0.2, 0.2), (0.2, 1, 0.2), (0.2, 0.2, 1), (1, 1, 0.2)]
+    mats["ambient"], mats["diffuse"], mats["specular"], mats["shininess"], mats["refractive_index"] = 0.1, 0.9, 0.9, 200.0, 1.0
+    groups = np.zeros(1, dtype=api.RTC_GROUP)
+    groups["first"], groups["count"] = 0, n
+    items = np.zeros(n, dtype=api.HREF)
+    items["kind"], items["index"] = api.O_TRIANGLE, np.arange(n)
+    objs = np.zeros(1, dtype=api.HREF)
+    objs["kind"], objs["index"] = api.O_GROUP, 0
+    lights = np.zeros(2, dtype=api.RTC_LIGHT)
+    lights["position"], lights["intensity"] = [(-4, 6, -8), (5, 3, -6)], [(0.8, 0.8, 0.8), (0.4, 0.4, 0.5)]
+    world = rl.RtcWorld.from_arrays(tri, mats, objs, lights, groups=groups, group_items=items)
+    for cam in (rl.rtc_camera(96, 64, 1.2, (0, 0, -7), (0, 0, 0), (0, 1, 0)),          # centre column / row: d.x == 0 or d.y == 0
+                rl.rtc_camera(64, 64, 0.9, (3, 2.5, -6), (0.2, 0, 0.5), (0, 1, 0))):
+        gs, cs = {}, {}
+        a = world.render(aa_samples=2, camera=cam, stats=gs)
+        b = oracle.rtc_render(world.desc, cam, aa=2, stats=cs)
+        assert np.abs(a - b).max() <= 1e-12
+        for k in ("rays", "node_tests", "planar_tests", "flagged"):
+            assert gs[k] == cs[k], (k, gs[k], cs[k])
