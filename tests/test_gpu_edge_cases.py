@@ -197,3 +197,24 @@ def test_rtc_triangle_guard_tree_keeps_order_ties_and_axis_parallel_rays(rl, ora
         assert np.abs(a - b).max() <= 1e-12
         for k in ("rays", "node_tests", "planar_tests", "flagged"):
             assert gs[k] == cs[k], (k, gs[k], cs[k])
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_coincident_spheres_resolve_ties_like_the_reference(rl, oracle, use_bvh):
+    """Two spheres with identical geometry but different materials: both hits have the same t, and which one wins is decided by
+    the evaluation order (sphere.rs:51-54 accepts t <= closest) — the guard ops and one-sphere LEAF visits must keep it."""
+    api = rl.api
+    tex = np.zeros(2, dtype=api.TEXTURE)
+    tex["kind"], tex["color"] = api.TEX_SOLID, [(0.9, 0.1, 0.1), (0.1, 0.1, 0.9)]
+    mats = np.zeros(3, dtype=api.MATERIAL)
+    mats[0]["kind"], mats[0]["texture"] = api.MAT_LAMBERTIAN, 0
+    mats[1]["kind"], mats[1]["texture"] = api.MAT_DIFFUSE_LIGHT, 1
+    mats[2]["kind"], mats[2]["albedo"], mats[2]["fuzz"] = api.MAT_METAL, (0.8, 0.8, 0.8), 0.1
+    sph = np.zeros(7, dtype=api.SPHERE)
+    sph["center0"] = [(0, 0, -3), (0, 0, -3), (1.5, 0, -3), (1.5, 0, -3), (-1.5, 0.2, -3.5), (-1.5, 0.2, -3.5), (0, -100.5, -3)]
+    sph["radius"] = [0.5, 0.5, 0.5, 0.5, 0.6, 0.6, 100.0]
+    sph["material"] = [0, 1, 1, 0, 2, 0, 0]
+    world = rl.World.from_spheres(sph, mats, tex, use_bvh)
+    p = rl.CameraParams(aspect_ratio=2.0, image_width=96, samples_per_pixel=4, max_depth=8, vfov=50.0, lookfrom=(0, 0.3, 1), lookat=(0, 0, -3),
+                        background=(0.6, 0.7, 0.9))
+    _check(rl, oracle, world, p)
