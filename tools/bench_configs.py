@@ -43,6 +43,14 @@ if "cfg3" in which:
         print(json.dumps({"config": "cfg3 RTC teapot 1920x1080", "aa": aa, "rays": st["rays"], "kernel_ms": st["kernel_ms"],
                           "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3, "tri_tests_per_ray": st["planar_tests"] / st["rays"],
                           "alg_GBps": alg / st["kernel_ms"] / 1e6, "max_abs_err_vs_oracle_rows": err}), flush=True)
+if "rtcfull" in which:  # not a BASELINE config: the reference's mirror / CSG integration scenes at 1920x1080 through the full color_at kernel
+    for name, w in (("RTC mirror scene 1920x1080", rl.RtcWorld.test_mirror_scene(1920, 1080)), ("RTC csg scene 1920x1080", rl.RtcWorld.test_csg_scene(1920, 1080))):
+        w.render(1)
+        st = {}
+        img = w.render(1, stats=st)
+        cpu = oracle.rtc_render(w.desc, w.camera, aa=1, row_first=0, row_step=60)
+        print(json.dumps({"config": name, "aa": 1, "rays": st["rays"], "kernel_ms": st["kernel_ms"], "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
+                          "max_abs_err_vs_oracle_rows": float(np.abs(img[0::60] - cpu).max())}), flush=True)
 if "cfg4" in which or "cfg5" in which:
     tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
     obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
