@@ -3,33 +3,48 @@
 
 Metric: Mrays/sec (primary + secondary) on the RTIOW random-sphere scene
 (examples/bouncing_spheres.rs: 488 spheres, 511-node BVH), 1920x1080, 1024 spp, depth 50 (configs[1]).
-A "step" = one full render of that frame through the C ABI (rl_rtiow_render_device), scene already
-resident in HBM, output left in HBM.  With N GPUs the framebuffer is sharded by interleaved rows
-(row r -> rank r mod N, no data-path collective during the render) and gathered to rank 0 over
-RCCL/xGMI once per step — inside the timed region.
+A "step" = one full render of that frame through the C ABI, scene already resident in HBM, output left in HBM.
+With N GPUs the framebuffer is sharded by interleaved rows (row r -> rank r mod N, no data-path collective during
+the render) and gathered to rank 0 over RCCL/xGMI once per step — inside the timed region.
+
+  python bench.py                          one GPU
+  torch.distributed.run ... bench.py --gpus N   one rank per GPU (the driver's form): rl_rtiow_render_device + dist.gather
+  python bench.py --gpus N                 (no launcher) starts exactly that launcher as a child process before touching a GPU
+  python bench.py --gpus N --inprocess     ONE process, the library's own multi-GPU entry point (rl_init_multi +
+                                           rl_rtiow_render_multi_device: RCCL send/recv inside the library)
+It never prints a line whose n_gpus differs from --gpus.
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline     — algorithmic bytes (64 B per AABB test + 64 B per sphere test + 208 B per ray, SURVEY.md
-                 §8d, counted by the kernel itself and equal to the CPU oracle's counts) / kernel time,
-                 against the 8 TB/s HBM peak.  The scene is LDS-resident, so the practical ceiling is
-                 FP64 VALU issue under divergence, not HBM — see DESIGN.md.
-  cpu_baseline — the CPU oracle (C++ restatement of the reference; the Rust reference cannot be built
-                 here) timed on this box's host cores over a bounded sample of the same workload.
+  roofline     — the kernel is VALU-issue-bound (the scene lives in LDS / L2; measured HBM traffic is the framebuffer), so the
+                 bound is the chip's vector-instruction issue capacity: achieved = VALU lane-operations per ray (rocprofv3 SQ
+                 counters of the same kernel on the same workload, profiles/valu.json: instruction counts are a property of the
+                 workload) x rays of THIS run / kernel time of THIS run (HIP events on the launch stream), binary64 instructions
+                 weighted 2x (they hold the pipe twice as long); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
+                 `traffic` = measured HBM bytes per launch (profiles/), algorithmic_bytes = SURVEY.md §8d's figure, both reported,
+                 neither the bound.
+  check        — after the timed loop: the timed frame equals the counting kernel's frame bit for bit; 8 full-spp rows of the real
+                 frame are re-rendered by the CPU oracle (counters exact, max |err| of the pixel means).
+  cpu_baseline — the CPU oracle (C++ restatement of the reference; the Rust reference cannot be built here) timed on this
+                 box's host cores over a bounded sample of the same workload.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_GHZ, N_CU, N_SIMD, SIMD_LANES = 2.4, 256, 4, 32  # /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters, SIMD-32)
+VALU_PEAK_TLANEOPS = N_CU * N_SIMD * SIMD_LANES * CLOCK_GHZ / 1e3  # 78.6 T lane-ops/s (one binary32 op per lane per clock)
+LDS_PEAK_GBS = N_CU * 128 * CLOCK_GHZ                             # 128 B/clk/CU
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -38,18 +53,56 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run frame check (profiling passes)")
+    ap.add_argument("--check-rows", type=int, default=8)
+    ap.add_argument("--inprocess", action="store_true", help="N GPUs from ONE process through rl_init_multi / rl_rtiow_render_multi_device")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU rehearsal of an N-way shard: render only rows 0 mod N (not the headline metric)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N fresh ranks under torch.distributed.run BEFORE this process touches a GPU."""
+    import torch
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to print a mislabelled line")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+def valu_profile(W, H, spp, depth):
+    """SQ-counter figures of the timed kernel on this workload (profiles/valu.json, written from tools/pmc.sh passes)."""
+    path = os.path.join(ROOT, "profiles", "valu.json")
+    try:
+        vj = json.load(open(path))
+    except Exception:
+        return None
+    return vj if vj.get("workload_scene") == "bouncing_spheres(1)" and vj.get("depth") == depth and vj.get("width") == W else None
+
+
+def main():
+    args = parse_args()
+    ws_env = os.environ.get("WORLD_SIZE")
+    if ws_env is None and args.gpus > 1 and not args.inprocess:
+        spawn_ranks(args)
+    world_size = int(ws_env) if ws_env is not None else 1
+    if args.inprocess:
+        if world_size != 1:
+            raise SystemExit("--inprocess is a single-process mode: do not start it under a launcher")
+    elif world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus and world_size > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # RL_BENCH_REHEARSAL=1: every rank uses GPU 0 and the gather goes over gloo through host memory — a way to run the
@@ -68,7 +121,14 @@ def main():
 
     rl = importlib.import_module("rendering-learning_amd")
     sharding = importlib.import_module("rendering-learning_amd.sharding")
-    rl.init(local_rank)
+    G = args.gpus if args.inprocess else world_size
+    if args.inprocess:
+        emu = int(os.environ.get("RL_BENCH_EMULATE_DEVICES", "0"))  # one-GPU box: G contexts on GPU 0 (NOT a measurement)
+        got = rl.api.init_multi(0 if emu else args.gpus, emulate=emu and args.gpus)
+        if got != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} --inprocess: the library drives {got} device(s)")
+    else:
+        rl.init(local_rank)
 
     # ---- workload: configs[1] of BASELINE.json
     world = rl.World.bouncing_spheres(1)
@@ -76,15 +136,13 @@ def main():
     p.image_width, p.samples_per_pixel, p.max_depth = args.width, args.spp, args.depth
     cam = rl.Camera(p)
     W, H = cam.c.image_width, cam.c.image_height
-    G = world_size
-    row_first, row_step = rank, G
+    row_first, row_step = (0, 1) if args.inprocess else (rank, G)
     if args.emulate_shard > 1:
         row_first, row_step = 0, args.emulate_shard
-    nrows = rl.api.rows_for(H, row_first, row_step)
     max_rows = rl.api.rows_for(H, 0, row_step)
     shard = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)
-    gathered = [torch.zeros_like(shard) for _ in range(G)] if (G > 1 and rank == 0) else None
-    frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = [torch.zeros_like(shard) for _ in range(G)] if (world_size > 1 and rank == 0) else None
+    frame = torch.zeros((H, W, 3), dtype=torch.float64, device=dev) if (rank == 0 and world_size > 1) else None
     stream = torch.cuda.current_stream(dev)
 
     def exchange():  # the one exchange step of the path: framebuffer rows -> rank 0 over RCCL/xGMI
@@ -96,17 +154,27 @@ def main():
             sharding.gather_frame(shard, H, rank, G, frame=frame, gathered=gathered)
 
     def step(stats=None):
+        if args.inprocess:  # the library renders on its own streams and gathers itself; rl_render_status waits
+            cam.render_multi_device(world, shard.data_ptr(), stats=stats)
+            return
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step, stats=stats)
-        if G > 1:
+        if world_size > 1:
             exchange()
 
-    # ---- counters for this exact workload (deterministic: identical for every launch) — untimed
+    def finish():
+        torch.cuda.synchronize(dev)
+        if args.inprocess:
+            return rl.api.render_status(world)
+        return None
+
+    # ---- counters for this exact workload (deterministic: identical for every launch) — untimed; keep the counting frame
     st = {}
     step(stats=st)
     torch.cuda.synchronize(dev)
+    counting_frame = (frame if world_size > 1 else shard).clone() if rank == 0 else None
     for _ in range(max(0, args.warmup - 1)):
         step()
-    torch.cuda.synchronize(dev)
+    finish()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -114,19 +182,27 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
+        if args.inprocess:
+            step()
+            continue
         evs[k][0].record(stream)
         cam.render_device(world, shard.data_ptr(), stream=stream.cuda_stream, row_first=row_first, row_step=row_step)
         evs[k][1].record(stream)
-        if G > 1:
+        if world_size > 1:
             exchange()
-    torch.cuda.synchronize(dev)
+    fin = finish()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
+    if args.inprocess:
+        kernel_ms = elapsed / max(1, args.steps) * 1e3  # wall per step (the library's streams are not torch's)
+        timed_status = fin
+    else:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
+        timed_status = rl.api.render_status(world)  # rays / flagged counted by the TIMED kernel itself (last step)
 
-    tot = torch.tensor([float(st["rays"]), float(st["node_tests"]), float(st["sphere_tests"]), elapsed, kernel_ms],
+    tot = torch.tensor([float(st["rays"]), float(st["node_tests"]), float(st["sphere_tests"]), elapsed, kernel_ms, float(timed_status["rays"])],
                        dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world_size > 1:
         mx = tot.clone()
@@ -136,76 +212,114 @@ def main():
         kernel_ms_max = float(mx[4])
     else:
         kernel_ms_max = kernel_ms
-    rays, nodes, spheres = float(tot[0]), float(tot[1]), float(tot[2])
+    rays, nodes, spheres, timed_rays = float(tot[0]), float(tot[1]), float(tot[2]), float(tot[5])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
-        # algorithmic bytes per launch on rank 0's kernel (per-rank share for N>1)
-        alg_bytes = (64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 208.0 * st["rays"])
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        rank_rays = float(st["rays"]) if not args.inprocess else rays / G  # rank 0's kernel (per-GPU share in-process)
+        k_s = kernel_ms * 1e-3
         launches = 2 if (args.spp >= 64 and os.environ.get("RL_LPT", "1") != "0") else 1
-        traffic, valu = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world_size == 1 and not args.emulate_shard:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == f"{W}x{H}x{args.spp}spp_d{args.depth}":
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    valu = tj.get("valu")  # SQ counters of the same kernel (profiles/): what actually binds it
-            except Exception:
-                traffic, valu = None, None
+        # SURVEY.md §8d's algorithmic bytes (what a scene-from-HBM traversal would move): reported, NOT the bound
+        alg_bytes = 64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 208.0 * st["rays"]
+        vp = valu_profile(W, H, args.spp, args.depth)
+        roof = {"bound": "valu", "unit": "Tlane-op/s", "peak": VALU_PEAK_TLANEOPS, "kernel": "rtiow_wave_kernel<1024,3,false>",
+                "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max, "launches_per_step": launches, "kernel_avg_launch_ms": kernel_ms / launches,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gbs": alg_bytes / k_s / 1e9, "traffic": None}
+        if vp:
+            lane_ops = vp["valu_lane_ops_per_ray_f32_weighted"]   # lanes x instructions, binary64 instructions counted twice
+            wave_insts = vp["valu_issue_slots_per_ray"]            # wave-instructions, binary64 counted twice (2-cycle slots)
+            achieved = lane_ops * rank_rays / k_s / 1e12
+            issue = wave_insts * rank_rays / k_s / (N_CU * N_SIMD * CLOCK_GHZ * 1e9 / 2.0)
+            lds_gbs = vp["lds_bytes_per_ray"] * rank_rays / k_s / 1e9
+            roof.update({"achieved": achieved, "frac": achieved / VALU_PEAK_TLANEOPS,
+                         "valu_issue_frac": issue, "lanes_active_frac": vp["lanes_active_frac"],
+                         "lds_gbs": lds_gbs, "lds_frac": lds_gbs / LDS_PEAK_GBS, "lds_bank_conflict_frac": vp["lds_bank_conflict_frac"],
+                         "fp64_flop_per_ray": vp.get("fp64_flop_per_ray"),
+                         "fp64_tflops": (vp["fp64_flop_per_ray"] * rank_rays / k_s / 1e12) if vp.get("fp64_flop_per_ray") else None,
+                         "traffic": vp.get("hbm_bytes_per_launch"),
+                         "per_ray_figures_from": vp.get("source"),
+                         "note": "per-ray instruction counts are rocprofv3 SQ counters of this kernel on this workload (profiles/, not collected in this run); "
+                                 "rays and kernel time are this run's. frac = valu_issue_frac x lanes_active_frac at the nominal 2.4 GHz; the scene is LDS / L2-resident, "
+                                 "HBM traffic is the framebuffer"})
+        else:
+            roof.update({"achieved": None, "frac": None, "note": "no profiles/valu.json for this workload: VALU figures not available"})
         out = {
             "metric": "Mrays/sec (primary+secondary), 1080p 1024spp depth50; 1/2/4/8 GPU",
-            "value": value, "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Mrays/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"RTIOW bouncing_spheres scene (488 spheres, 511-node BVH), {W}x{H}, {args.spp} spp, depth {args.depth}, seed 0",
-                       "baseline_config": "configs[1]", "sharding": f"rows interleaved over {world_size} rank(s), RCCL gather to rank 0",
+                       "baseline_config": "configs[1]",
+                       "sharding": (f"one process, rl_rtiow_render_multi_device over {G} GPU(s): rows interleaved, RCCL send/recv to GPU 0 inside the library" if args.inprocess
+                                    else f"rows interleaved over {G} rank(s), RCCL gather to rank 0"),
                        "rays_per_step": rays, "aabb_tests_per_ray": nodes / rays, "sphere_tests_per_ray": spheres / rays},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rtiow_wave_kernel", "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # spp >= 64: one render = two launches of the same kernel (8-sample cost probe + cost-sorted remainder);
-                         # kernel_ms spans both, so rocprofv3's per-launch average = kernel_ms / launches_per_step
-                         "launches_per_step": launches, "kernel_avg_launch_ms": kernel_ms / launches,
-                         "valu_counters": valu,
-                         "note": "scene is LDS / L2-resident: real HBM traffic is the framebuffer; the binding resource is VALU issue under divergence (valu_counters)"},
+            "roofline": roof,
         }
         if args.emulate_shard > 1:
             out["config"]["emulated_shard_of"] = args.emulate_shard
-        if rehearsal:
-            out["config"]["rehearsal"] = "all ranks on GPU 0, gloo gather through host memory: NOT a measurement"
-            # the assembled frame must equal a single-rank render of the same frame
-            ref = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
-            cam.render_device(world, ref.data_ptr(), stream=stream.cuda_stream)
-            torch.cuda.synchronize(dev)
-            out["config"]["rehearsal_frame_equal"] = bool(torch.equal(ref, frame))
-        if world_size == 1 and not args.no_cpu_baseline:
+        if rehearsal or (args.inprocess and os.environ.get("RL_BENCH_EMULATE_DEVICES")):
+            out["config"]["rehearsal"] = "all ranks / device contexts on GPU 0: NOT a measurement"
+        # ---- the check: the TIMED frame against the counting kernel's frame and against the CPU oracle at full spp
+        if not args.no_check:
+            timed_frame = frame if world_size > 1 else shard
+            chk = {"timed_frame_equals_counting_frame": bool(torch.equal(timed_frame, counting_frame)),
+                   "timed_rays_equal_counting_rays": timed_rays == rays, "flagged": int(st["flagged"])}
+            full_rows = world_size > 1 or args.inprocess or args.emulate_shard <= 1  # timed_frame holds every image row
+            rows = max(0, min(args.check_rows, H))
+            if rows and full_rows:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                oracle = importlib.import_module("rl_oracle")
+                cstep = max(1, H // rows)
+                cfirst = cstep // 2
+                ys = np.arange(cfirst, H, cstep, dtype=np.uint32)
+                # the same rows once more on the GPU as a row shard with the counting kernel: counters for exactly these rows
+                rows_buf = torch.zeros((len(ys), W, 3), dtype=torch.float64, device=dev)
+                rs = {}
+                single = rl.World.bouncing_spheres(1) if args.inprocess else world
+                if args.inprocess:
+                    rl.init(0)  # back to one context for the row-shard render
+                    single = rl.World.bouncing_spheres(1)
+                cam.render_device(single, rows_buf.data_ptr(), stream=stream.cuda_stream, row_first=cfirst, row_step=cstep, stats=rs)
+                torch.cuda.synchronize(dev)
+                gx, gy = np.meshgrid(np.arange(W, dtype=np.uint32), ys)
+                cs = {}
+                c0 = time.perf_counter()
+                cpu = oracle.rtiow_render_pixels(world.desc, cam.c, gx.ravel(), gy.ravel(), stats=cs).reshape(len(ys), W, 3)
+                cdt = time.perf_counter() - c0
+                timed_rows = timed_frame[torch.as_tensor(ys.astype(np.int64), device=dev)]
+                chk.update({"rows_checked": int(len(ys)), "rows": [int(y) for y in ys], "pixels_checked": int(len(ys) * W), "spp": args.spp,
+                            "timed_rows_equal_row_shard_render": bool(torch.equal(timed_rows, rows_buf)),
+                            "counters_equal": all(int(rs[k]) == int(cs[k]) for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged")),
+                            "max_abs_err": float(np.abs(timed_rows.cpu().numpy() - cpu).max() / max(1, args.spp)),
+                            "tolerance": 1e-4, "oracle_seconds": cdt})
+            out["check"] = chk
+        if world_size == 1 and not args.inprocess and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             oracle = importlib.import_module("rl_oracle")
             try:
                 threads = min(oracle.hardware_threads(), len(os.sched_getaffinity(0)))
             except AttributeError:
                 threads = oracle.hardware_threads()
-            # bounded sample, sized for ~15 s of CPU work: every 2nd row (so every thread has rows), spp
-            # calibrated from a 1-spp probe of the same rows
+            # bounded sample, sized for ~15 s of CPU work: every 2nd row, one task per PIXEL (no straggler rows), spp
+            # calibrated from a 1-spp probe of the same pixels
             cstep = 2
+            gx, gy = np.meshgrid(np.arange(W, dtype=np.uint32), np.arange(0, H, cstep, dtype=np.uint32))
+            gx, gy = gx.ravel(), gy.ravel()
             probe = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": 1}))
-            pst = {}
             c0 = time.perf_counter()
-            oracle.rtiow_render(world.desc, probe.c, row_first=0, row_step=cstep, threads=threads, stats=pst)
+            oracle.rtiow_render_pixels(world.desc, probe.c, gx, gy, threads=threads)
             pdt = max(time.perf_counter() - c0, 1e-3)
             cspp = int(max(1, min(args.spp, 15.0 / pdt)))
             ccam = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": cspp}))
             cst = {}
             c0 = time.perf_counter()
-            oracle.rtiow_render(world.desc, ccam.c, row_first=0, row_step=cstep, threads=threads, stats=cst)
+            oracle.rtiow_render_pixels(world.desc, ccam.c, gx, gy, threads=threads, stats=cst)
             cdt = time.perf_counter() - c0
             out["cpu_baseline"] = {"value": cst["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"same scene/camera {W}x{H} depth {args.depth}: rows y%{cstep}==0 ({rl.api.rows_for(H, 0, cstep)} rows), "
-                                             f"{cspp} spp, {cst['rays']} rays in {cdt:.1f} s on {threads} threads; CPU restatement of the "
-                                             "reference algorithm (oracle/), not the Rust reference"}
+                                             f"{cspp} spp, {cst['rays']} rays in {cdt:.1f} s on {threads} threads (one task per pixel); CPU restatement of the "
+                                             "reference algorithm (oracle/, -O3 -ffp-contract=off), not the Rust reference"}
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 3
+#define RL_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ errors */
 #define RL_OK 0
@@ -44,8 +44,16 @@ extern "C" {
 #define RL_E_NOMEM (-6)
 
 /* ------------------------------------------------------------------ lifetime */
-/* device < 0: keep the process's current HIP device. One process drives one GPU. */
+/* device < 0: keep the process's current HIP device.  One GPU (use this form for one process per GPU, e.g. under
+ * torch.distributed / MPI, with rl_*_render_device + the caller's own gather). */
 int rl_init(int device);
+/* One process, n_devices GPUs (0 = every visible one): the reference calls ONE Camera::render(&world) from one thread
+ * (ray-tracing-one-weekend/src/camera.rs:122, examples/common/mod.rs:16; ray-tracer-challenge/src/scene/camera.rs:93), so a drop-in
+ * host reaches all GPUs of the node through rl_*_render_multi.  The library owns one stream per device and the RCCL communicators
+ * (ncclCommInitAll, one rank per GPU; librccl is dlopen'ed here, a single-GPU host never loads it).  Scenes created AFTERWARDS are
+ * replicated on every device. */
+int rl_init_multi(int n_devices);
+int rl_device_count(void); /* device contexts the library drives: 1 after rl_init, n after rl_init_multi, 0 before either */
 void rl_shutdown(void);
 const char *rl_last_error(void); /* thread-local, owned by the library */
 int rl_abi_version(void);
@@ -228,6 +236,20 @@ int rl_rtiow_render_device(const rl_scene *, const rl_rtiow_camera *, uint64_t f
                            uint32_t row_first, uint32_t row_step, void *d_out_rgb_sum,
                            void *hip_stream, rl_stats *opt_stats);
 
+/* Completion + status of the last ASYNCHRONOUS render of this scene (rl_*_render_device / rl_*_render_multi_device with
+ * opt_stats == NULL): waits for it, fills opt_stats->rays and ->flagged (the other counters need a counting render) and returns
+ * RL_E_DEGENERATE if a reference panic site (camera.rs:86, material.rs:151, vec3.rs:220, ...) was reached, else RL_OK. */
+int rl_render_status(const rl_scene *, rl_stats *opt_stats);
+
+/* Camera::render on every GPU of rl_init_multi: image row r is rendered by GPU r mod G with the single-GPU
+ * kernels (no collective during the render), then ONE exchange — ncclSend / ncclRecv of ceil(H/G)*W*3 f64 per peer to GPU 0 in one
+ * RCCL group, each peer over its own xGMI link — and a de-interleave kernel on GPU 0.  The frame is bit-identical for every G.
+ * out_rgb_sum: host buffer, W*H*3 doubles (Canvas.data order, sums).  With G = 1 this is rl_rtiow_render. */
+int rl_rtiow_render_multi(const rl_scene *, const rl_rtiow_camera *, uint64_t first_sample, double *out_rgb_sum, rl_stats *opt_stats);
+/* Same with the frame left in GPU 0's HBM (d_out_rgb_sum: device pointer on device 0).  Asynchronous on the library's streams
+ * unless opt_stats is non-NULL; rl_render_status(scene) waits for the frame. */
+int rl_rtiow_render_multi_device(const rl_scene *, const rl_rtiow_camera *, uint64_t first_sample, void *d_out_rgb_sum, rl_stats *opt_stats);
+
 /* Output stage on the device (color.rs:22-57, output.rs:5-14): mean = sum * (1/samples), linear_to_srgb,
  * floor(v * 255.999) clamped to 0..255.  d_rgb_sum / d_rgb8 are DEVICE pointers (n_pixels*3 f64 / u8). */
 int rl_rtiow_encode_rgb8_device(const void *d_rgb_sum, uint64_t n_pixels, uint32_t samples, void *d_rgb8, void *hip_stream);
@@ -350,6 +372,10 @@ int rl_rtc_render_rows(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samp
 int rl_rtc_render_device(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samples,
                          uint32_t row_first, uint32_t row_step, void *d_out_rgb, void *hip_stream,
                          rl_stats *opt_stats);
+
+/* Camera::render(&world, opts) over every GPU of rl_init_multi: rows interleaved, one RCCL exchange to GPU 0 (see rl_rtiow_render_multi). */
+int rl_rtc_render_multi(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samples, double *out_rgb, rl_stats *opt_stats);
+int rl_rtc_render_multi_device(const rl_scene *, const rl_rtc_camera *, uint32_t aa_samples, void *d_out_rgb, rl_stats *opt_stats);
 
 /* Output stage on the device (draw/canvas.rs:53-56): round(c * 255) (half away from zero) clamped to 0..255. */
 int rl_rtc_encode_rgb8_device(const void *d_rgb, uint64_t n_pixels, void *d_rgb8, void *hip_stream);

@@ -1155,6 +1155,88 @@ int rlo_rtiow_render_rows(const rl_rtiow_scene_desc *desc, const rl_rtiow_camera
   store_stats(stats, tot, 0.0);
   return tot.flagged ? RL_E_DEGENERATE : RL_OK;
 }
+// The same per-pixel loop over an explicit pixel list (xs[i], ys[i]), one task per PIXEL: bench.py's full-spp spot check of the
+// timed frame and its cpu_baseline leg (a row is too coarse a task for 256 host threads).  out: n x 3 sums.
+int rlo_rtiow_render_pixels(const rl_rtiow_scene_desc *desc, const rl_rtiow_camera *cam, uint64_t first_sample, const uint32_t *xs, const uint32_t *ys,
+                            uint32_t n, int threads, double *out, rl_stats *stats) {
+  if (!desc || !cam || !out || (n && (!xs || !ys))) return RL_E_INVALID;
+  for (uint32_t i = 0; i < n; i++)
+    if (xs[i] >= cam->image_width || ys[i] >= cam->image_height) return RL_E_INVALID;
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  std::vector<Counters> per(threads > 0 ? threads : 1);
+  parallel_rows(n, threads, [&](uint32_t i, int t) {
+    RtiowCtx cx{desc, Counters{}};
+    rtiow_pixel(cx, *cam, first_sample, xs[i], ys[i], out + (size_t)i * 3);
+    add_counters(per[t], cx.c);
+  });
+  Counters tot;
+  for (auto &c : per) add_counters(tot, c);
+  store_stats(stats, tot, 0.0);
+  return tot.flagged ? RL_E_DEGENERATE : RL_OK;
+}
+// Bvh::new (RTIOW bvh.rs:22-60) + find_longest_axis (bvh.rs:63-77) restated as the plain recursion the reference runs, on
+// the hittables' bounding boxes (what Hittable::bounding_box() returns).  Output = rl_bvh_build's format (include/rl_render.h):
+// nodes in creation order (node, left subtree, right subtree), children of inner nodes as RL_H_BVH node_base + index.
+// bvh.rs:49 sorts with sort_unstable_by, whose order among EQUAL keys is implementation-defined; this restatement (like the
+// product) uses a stable sort on f64::total_cmp keys — the documented variant, unpinned by any reference fixture.
+namespace {
+struct BvhBuilder {
+  const double *boxes;
+  const rl_href *prims;
+  uint32_t node_base;
+  std::vector<rl_bvh_node> out;
+  static bool total_less(double a, double b) {  // f64::total_cmp(a, b) == Less
+    int64_t x, y;
+    std::memcpy(&x, &a, 8), std::memcpy(&y, &b, 8);
+    x ^= (int64_t)((uint64_t)(x >> 63) >> 1), y ^= (int64_t)((uint64_t)(y >> 63) >> 1);
+    return x < y;
+  }
+  uint32_t build(std::vector<uint32_t> hs) {
+    const uint32_t idx = (uint32_t)out.size();
+    out.push_back(rl_bvh_node{});
+    rl_bvh_node nd{};
+    auto merge_into = [&](double *b, uint32_t h) {  // AABB::merge (aabb.rs:135-140): Interval::merge per axis, f64::min / max
+      for (int ax = 0; ax < 3; ax++) b[2 * ax] = std::fmin(b[2 * ax], boxes[6 * (size_t)h + 2 * ax]), b[2 * ax + 1] = std::fmax(b[2 * ax + 1], boxes[6 * (size_t)h + 2 * ax + 1]);
+    };
+    if (hs.size() == 1) {  // bvh.rs:27-30
+      for (int k = 0; k < 6; k++) nd.bbox[k] = boxes[6 * (size_t)hs[0] + k];
+      nd.n_children = 1, nd.child[0] = prims[hs[0]];
+    } else if (hs.size() == 2) {  // bvh.rs:31-35: left.bounding_box().merge(&right.bounding_box())
+      for (int k = 0; k < 6; k++) nd.bbox[k] = boxes[6 * (size_t)hs[0] + k];
+      merge_into(nd.bbox, hs[1]);
+      nd.n_children = 2, nd.child[0] = prims[hs[0]], nd.child[1] = prims[hs[1]];
+    } else {
+      for (int ax = 0; ax < 3; ax++) nd.bbox[2 * ax] = INFINITY, nd.bbox[2 * ax + 1] = -INFINITY;  // AABB::empty()
+      for (uint32_t h : hs) merge_into(nd.bbox, h);                                                   // bvh.rs:37-39
+      double sx = nd.bbox[1] - nd.bbox[0], sy = nd.bbox[3] - nd.bbox[2], sz = nd.bbox[5] - nd.bbox[4];
+      int axis = sx > sy ? (sx > sz ? 0 : 2) : (sy > sz ? 1 : 2);  // bvh.rs:63-77
+      std::stable_sort(hs.begin(), hs.end(), [&](uint32_t l, uint32_t r) { return total_less(boxes[6 * (size_t)l + 2 * axis], boxes[6 * (size_t)r + 2 * axis]); });
+      size_t mid = hs.size() / 2;  // bvh.rs:51-53
+      std::vector<uint32_t> ls(hs.begin(), hs.begin() + (long)mid), rs(hs.begin() + (long)mid, hs.end());
+      hs.clear();
+      hs.shrink_to_fit();
+      uint32_t l = build(std::move(ls));
+      uint32_t r = build(std::move(rs));
+      nd.n_children = 2;
+      nd.child[0] = rl_href{RL_H_BVH, node_base + l}, nd.child[1] = rl_href{RL_H_BVH, node_base + r};
+    }
+    out[idx] = nd;
+    return idx;
+  }
+};
+}  // namespace
+int rlo_bvh_build(const double *prim_boxes, const rl_href *prims, uint32_t n, uint32_t node_base, rl_bvh_node *out_nodes, uint32_t cap, uint32_t *out_n_nodes) {
+  if (!prim_boxes || !prims || !out_nodes || n == 0) return RL_E_INVALID;  // bvh.rs:23-25 panics on an empty list
+  BvhBuilder b{prim_boxes, prims, node_base, {}};
+  std::vector<uint32_t> all(n);
+  for (uint32_t i = 0; i < n; i++) all[i] = i;
+  b.build(std::move(all));
+  if (out_n_nodes) *out_n_nodes = (uint32_t)b.out.size();
+  if (b.out.size() > cap) return RL_E_INVALID;
+  std::memcpy(out_nodes, b.out.data(), b.out.size() * sizeof(rl_bvh_node));
+  return RL_OK;
+}
+
 int rlo_rtiow_render(const rl_rtiow_scene_desc *desc, const rl_rtiow_camera *cam, uint64_t first_sample, int threads, double *out, rl_stats *stats) {
   return rlo_rtiow_render_rows(desc, cam, first_sample, 0, 1, threads, out, stats);
 }

@@ -27,6 +27,8 @@ def lib():
         L = C.CDLL(LIB)
         vp, u64, u32, i32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
         L.rlo_rtiow_render_rows.argtypes = [vp, vp, u64, u32, u32, i32, vp, C.POINTER(Stats)]
+        L.rlo_rtiow_render_pixels.argtypes = [vp, vp, u64, vp, vp, u32, i32, vp, C.POINTER(Stats)]
+        L.rlo_bvh_build.argtypes = [vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
         L.rlo_rtc_render_rows.argtypes = [vp, vp, u32, u32, u32, i32, vp, C.POINTER(Stats)]
         L.rlo_chacha_key.argtypes = [u64, vp]
         L.rlo_chacha_block.argtypes = [u64, u64, u64, vp]
@@ -66,6 +68,38 @@ def rtiow_render(desc, cam, first_sample=0, row_first=0, row_step=1, threads=0, 
         stats.update(st.as_dict())
         stats["rc"] = rc
     return out
+
+
+def rtiow_render_pixels(desc, cam, xs, ys, first_sample=0, threads=0, stats=None):
+    """The per-pixel loop over an explicit pixel list, one task per pixel. Returns [n, 3] sums."""
+    xs = np.ascontiguousarray(xs, dtype=np.uint32)
+    ys = np.ascontiguousarray(ys, dtype=np.uint32)
+    assert xs.shape == ys.shape and xs.ndim == 1
+    out = np.empty((len(xs), 3), dtype=np.float64)
+    st = Stats()
+    rc = lib().rlo_rtiow_render_pixels(desc, C.addressof(cam), first_sample, xs.ctypes.data, ys.ctypes.data, len(xs), threads, out.ctypes.data, C.byref(st))
+    if rc not in (0, -5):
+        raise RuntimeError(f"oracle rtiow render_pixels rc={rc}")
+    if stats is not None:
+        stats.update(st.as_dict())
+        stats["rc"] = rc
+    return out
+
+
+BVH_NODE = np.dtype([("bbox", "<f8", 6), ("n_children", "<u4"), ("reserved", "<u4"), ("child", [("kind", "<u4"), ("index", "<u4")], 2)])
+
+
+def bvh_build(prim_boxes, prims, node_base=0):
+    """Bvh::new restated (bvh.rs:22-77). prim_boxes [n, 6] f64, prims [n] (kind, index) -> rl_bvh_node records."""
+    boxes = np.ascontiguousarray(prim_boxes, dtype=np.float64)
+    prims = np.ascontiguousarray(prims)
+    n = len(prims)
+    out = np.zeros(max(1, 2 * n), dtype=BVH_NODE)
+    cnt = C.c_uint32()
+    rc = lib().rlo_bvh_build(boxes.ctypes.data, prims.ctypes.data, n, node_base, out.ctypes.data, len(out), C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(f"oracle bvh_build rc={rc}")
+    return out[:cnt.value]
 
 
 def rtc_render(desc, cam, aa=1, row_first=0, row_step=1, threads=0, stats=None):

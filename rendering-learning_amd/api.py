@@ -21,7 +21,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-RENDER_LIB = os.path.join(_HERE, "csrc", "librl_render.so")
+# RL_RENDER_LIB selects another build of the same ABI (csrc/librl_render_exp.so: + the experimental kernel variants, A/B runs only)
+RENDER_LIB = os.environ.get("RL_RENDER_LIB") or os.path.join(_HERE, "csrc", "librl_render.so")
 HOST_LIB = os.path.join(_HERE, "host", "librl_host.so")
 
 RL_OK, RL_E_INVALID, RL_E_NO_DEVICE, RL_E_DEVICE, RL_E_UNSUPPORTED, RL_E_DEGENERATE, RL_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -146,11 +147,12 @@ def host_lib():
 
 
 # every symbol include/rl_render.h declares (checked by tests/test_abi.py)
-RENDER_SYMBOLS = ["rl_init", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info", "rl_scene_destroy",
+RENDER_SYMBOLS = ["rl_init", "rl_init_multi", "rl_device_count", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info",
+                  "rl_scene_destroy", "rl_render_status",
                   "rl_rtiow_scene_create", "rl_bvh_build", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
-                  "rl_rtiow_encode_rgb8_device", "rl_rtiow_render_rgb8",
+                  "rl_rtiow_render_multi", "rl_rtiow_render_multi_device", "rl_rtiow_encode_rgb8_device", "rl_rtiow_render_rgb8",
                   "rl_rtc_scene_create", "rl_rtc_render", "rl_rtc_render_rows", "rl_rtc_render_device",
-                  "rl_rtc_encode_rgb8_device", "rl_rtc_render_rgb8"]
+                  "rl_rtc_render_multi", "rl_rtc_render_multi_device", "rl_rtc_encode_rgb8_device", "rl_rtc_render_rgb8"]
 
 
 def render_lib():
@@ -179,6 +181,12 @@ def render_lib():
         L.rl_rtc_render.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtc_render_rows.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         L.rl_rtc_render_device.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.rl_init_multi.argtypes = [C.c_int]
+        L.rl_render_status.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_render_multi.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtiow_render_multi_device.argtypes = [C.c_void_p, C.POINTER(RtiowCamera), C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_render_multi.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
+        L.rl_rtc_render_multi_device.argtypes = [C.c_void_p, C.POINTER(RtcCamera), C.c_uint32, C.c_void_p, C.POINTER(Stats)]
         _render = L
     return _render
 
@@ -193,6 +201,34 @@ def init(device=-1):
     if rc != RL_OK:
         raise RLError(rc, L.rl_last_error().decode())
     _inited = True
+
+
+def init_multi(n_devices=0, emulate=0):
+    """rl_init_multi: one process drives n_devices GPUs (0 = all).  emulate=G (tests on a one-GPU box): G device contexts on the
+    current GPU.  Scenes must be (re)created afterwards so that every context holds a replica."""
+    global _inited
+    L = render_lib()
+    if emulate:
+        L.rl_debug_init_multi_emulated.argtypes = [C.c_int]
+        rc = L.rl_debug_init_multi_emulated(int(emulate))
+    else:
+        rc = L.rl_init_multi(int(n_devices))
+    if rc != RL_OK:
+        raise RLError(rc, L.rl_last_error().decode())
+    _inited = True
+    return L.rl_device_count()
+
+
+def render_status(world, allow_degenerate=False):
+    """rl_render_status: waits for the scene's last asynchronous render; {'rays', 'flagged', 'rc'}."""
+    st = Stats()
+    rc = render_lib().rl_render_status(world.device(), C.byref(st))
+    _check(rc, allow_degenerate)
+    return {"rays": st.rays, "flagged": st.flagged, "rc": rc}
+
+
+def has_experimental():
+    return bool(render_lib().rl_debug_has_experimental())
 
 
 def _check(rc, allow_degenerate=False):
@@ -535,6 +571,25 @@ class Camera:
     def render_rows(self, world: World, row_first, row_step, first_sample=0, stats=None):
         return self._render(first_sample, world, row_first, row_step, stats)
 
+    def render_multi(self, world: World, first_sample=0, stats=None, allow_degenerate=False) -> Canvas:
+        """rl_rtiow_render_multi: the whole frame over every GPU of init_multi (rows interleaved, one RCCL exchange)."""
+        out = np.empty((self.c.image_height, self.c.image_width, 3), dtype=np.float64)
+        st = Stats()
+        rc = render_lib().rl_rtiow_render_multi(world.device(), C.byref(self.c), first_sample, out.ctypes.data, C.byref(st))
+        _check(rc, allow_degenerate)
+        if stats is not None:
+            stats.update(st.as_dict())
+            stats["rc"] = rc
+        return Canvas(self.params.samples_per_pixel, self.c.image_width, self.c.image_height, out)
+
+    def render_multi_device(self, world: World, d_ptr, first_sample=0, stats=None):
+        """Frame left in GPU 0's HBM; asynchronous unless stats is a dict (api.render_status(world) waits)."""
+        st = Stats() if stats is not None else None
+        rc = render_lib().rl_rtiow_render_multi_device(world.device(), C.byref(self.c), first_sample, C.c_void_p(d_ptr), C.byref(st) if st is not None else None)
+        _check(rc)
+        if stats is not None:
+            stats.update(st.as_dict())
+
     def render_device(self, world: World, d_ptr, stream=0, row_first=0, row_step=1, first_sample=0, stats=None):
         """Output stays in HBM: d_ptr = device pointer of nrows*W*3 f64. Async unless stats is a dict."""
         st = Stats() if stats is not None else None
@@ -654,6 +709,18 @@ class RtcWorld:
         cam = camera or self.camera
         out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.uint8)
         _check(render_lib().rl_rtc_render_rgb8(self.device(), C.byref(cam), aa_samples, out.ctypes.data, None), allow_degenerate=True)
+        return out
+
+    def render_multi(self, aa_samples=1, camera=None, stats=None, allow_degenerate=False):
+        """rl_rtc_render_multi: the whole frame over every GPU of init_multi."""
+        cam = camera or self.camera
+        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+        st = Stats()
+        rc = render_lib().rl_rtc_render_multi(self.device(), C.byref(cam), aa_samples, out.ctypes.data, C.byref(st))
+        _check(rc, allow_degenerate)
+        if stats is not None:
+            stats.update(st.as_dict())
+            stats["rc"] = rc
         return out
 
     def render_device(self, d_ptr, aa_samples=1, camera=None, stream=0, row_first=0, row_step=1, stats=None):

@@ -15,7 +15,7 @@
 //
 // LDS: [linked ops][spheres][ChaCha rings 16 x NT u64][ray records 7 x NT f64][status NT u32][prim NT u32].
 #pragma once
-#include "rl_rtiow_wave.h"
+#include "../rl_rtiow_wave.h"
 
 namespace rl {
 

@@ -23,7 +23,7 @@
 // one-context form of the same restartable RNG (TWO = false) is slower too (3.33): every bail-out is an extra visit of
 // GEN / SHADE, which lowers all populations.  Kept selectable (RL_RTIOW_KERNEL=wave2) as the measured alternative.
 #pragma once
-#include "rl_rtiow_wave.h"
+#include "../rl_rtiow_wave.h"
 
 namespace rl {
 

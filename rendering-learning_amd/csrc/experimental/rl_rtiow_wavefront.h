@@ -20,7 +20,7 @@
 // per-pixel ray chain, so it does not improve strong scaling either.  Kept as the measured alternative that
 // DESIGN.md §3.5 discusses; the default kernel is rl_rtiow_wave.h.
 #pragma once
-#include "rl_rtiow_wave.h"
+#include "../rl_rtiow_wave.h"
 
 namespace rl {
 

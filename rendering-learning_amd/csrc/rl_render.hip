@@ -1,8 +1,10 @@
-// rl_render.hip — the C ABI of include/rl_render.h over the gfx950 kernels.
+// rl_render.hip — the C ABI of include/rl_render.h over the gfx950 kernels (single-device entry points; rl_multi.hip drives
+// several GPUs from one process on top of the launch halves defined here).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
 // No CPU fallback: every compute entry point fails with RL_E_NO_DEVICE unless rl_init succeeded on a GPU.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -12,16 +14,18 @@
 #include <string>
 #include <vector>
 
-#include "rl_program.h"
+#include "rl_scene.h"
 #include "rl_rtc_kernel.h"
 #include "rl_rtc_full_kernel.h"
 #include "rl_rtiow_kernel.h"
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
 #include "rl_rtiow_wave_general.h"
-#include "rl_rtiow_pool.h"
-#include "rl_rtiow_wave2.h"
-#include "rl_rtiow_wavefront.h"
+#ifdef RL_EXPERIMENTAL  // the measured-and-lost restructurings: only in librl_render_exp.so, never in the product library
+#include "experimental/rl_rtiow_pool.h"
+#include "experimental/rl_rtiow_wave2.h"
+#include "experimental/rl_rtiow_wavefront.h"
+#endif
 
 using namespace rl;
 
@@ -30,12 +34,11 @@ namespace {
 thread_local std::string g_err;
 std::mutex g_mu;
 bool g_ready = false;
-int g_device = -1;
+std::vector<DevCtx> g_ctx;  // [0] is the device rl_init chose; rl_init_multi appends the others
 int g_cus = 0;
 size_t g_lds_max = 65536;
-hipStream_t g_stream = nullptr;  // library-owned stream for the host-buffer entry points
-int g_rtiow_variant = 0;         // 0 = automatic; see RL_RTIOW_KERNEL in rl_rtiow_render_device
-bool g_lpt = true;               // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
+int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
+bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
 
 int set_err(int code, const std::string &m) {
   g_err = m;
@@ -74,62 +77,70 @@ __global__ void encode_rtc_rgb8(const double *rgb, unsigned long long n_vals, un
   out[i] = (unsigned char)(q < 0 ? 0 : (q > 255 ? 255 : q));
 }
 
+int init_context(DevCtx &c, int device) {
+  c.device = device;
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_err(RL_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+  g_cus = prop.multiProcessorCount;
+  g_lds_max = prop.sharedMemPerBlock > 65536 ? prop.sharedMemPerBlock : 65536;
+  if (prop.maxSharedMemoryPerMultiProcessor > g_lds_max) g_lds_max = prop.maxSharedMemoryPerMultiProcessor;
+  if (g_lds_max > 163840) g_lds_max = 163840;
+  if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  if (!c.ev) HIP_TRY(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+  return RL_OK;
+}
+
 }  // namespace
 
 namespace rl {
-int set_err_public(int code, const std::string &m) { return set_err(code, m); }  // for rl_bvh_build.hip
+int set_err_public(int code, const std::string &m) { return set_err(code, m); }  // for rl_bvh_build.hip / rl_multi.hip
+bool lib_ready() { return g_ready; }
+int n_contexts() { return (int)g_ctx.size(); }
+DevCtx &context(int i) { return g_ctx[(size_t)i]; }
+int use_context(int i) {
+  HIP_TRY(hipSetDevice(g_ctx[(size_t)i].device));
+  return RL_OK;
+}
+// rl_multi.hip: (re)build the context list — devices[g] for context g; context 0 keeps its stream when the device is unchanged
+int set_contexts(const std::vector<int> &devices) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (size_t i = devices.size(); i < g_ctx.size(); i++) {
+    if (g_ctx[i].stream && hipSetDevice(g_ctx[i].device) == hipSuccess) hipStreamDestroy(g_ctx[i].stream), hipEventDestroy(g_ctx[i].ev);
+  }
+  g_ctx.resize(devices.size());
+  for (size_t i = 0; i < devices.size(); i++) {
+    if (g_ctx[i].stream && g_ctx[i].device != devices[i]) {
+      hipSetDevice(g_ctx[i].device);
+      hipStreamDestroy(g_ctx[i].stream), hipEventDestroy(g_ctx[i].ev);
+      g_ctx[i] = DevCtx{};
+    }
+    int rc = init_context(g_ctx[i], devices[i]);
+    if (rc != RL_OK) return rc;
+  }
+  if (!g_ctx.empty()) hipSetDevice(g_ctx[0].device);
+  return RL_OK;
+}
 int sort_tiles_by_cost_desc(const uint32_t *d_cost, uint32_t *d_keys_tmp, uint32_t *d_order_in, uint32_t *d_order_out, uint32_t n, void **temp, size_t *temp_bytes,
                             hipStream_t stream);  // rl_bvh_build.hip (hipCUB)
+void add_stats(rl_stats *acc, const rl_stats &s) {
+  acc->rays += s.rays, acc->node_tests += s.node_tests, acc->sphere_tests += s.sphere_tests, acc->planar_tests += s.planar_tests;
+  acc->instance_enters += s.instance_enters, acc->rng_words += s.rng_words, acc->flagged += s.flagged;
+  acc->kernel_ms = std::max(acc->kernel_ms, s.kernel_ms);
+}
 }  // namespace rl
 
-struct rl_scene {
-  int kind;  // 1 = RTIOW, 2 = RTC
-  // RTIOW
-  RtiowProgram rt;
-  DevOp *d_ops = nullptr;
-  DevOp *d_lops = nullptr;  // linked form of the ops for the wave kernel (sphere-only scenes)
-  DevMaterial *d_sphere_flat = nullptr;  // per-sphere flattened materials for the wave kernel
-  uint32_t entry0 = 0;
-  CompactOp *d_cops = nullptr;  // guarded 32-byte ops (wave kernel, LDS_SCENE = 3)
-  uint32_t *d_movbits = nullptr;
-  uint32_t n_cops = 0, centry0 = 0;
-  DevSphere *d_spheres = nullptr;
-  uint32_t *d_sphere_material = nullptr;
-  DevPlanar *d_planars = nullptr;
-  rl_translate *d_translates = nullptr;
-  rl_transform *d_transforms = nullptr;
-  DevMaterial *d_materials = nullptr;
-  DevTexture *d_textures = nullptr;
-  DevImage *d_images = nullptr;
-  float *d_image_pool = nullptr;
-  rl_perlin *d_perlins = nullptr;
-  // RTC
-  RtcProgram rc;
-  DevTri *d_tris = nullptr;
-  rl_rtc_transformed *d_xforms = nullptr;
-  rl_rtc_material *d_rmaterials = nullptr;
-  rl_rtc_light *d_lights = nullptr;
-  rl_rtc_shape *d_shapes = nullptr;
-  rl_rtc_csg *d_csgs = nullptr;
-  rl_rtc_pattern *d_patterns = nullptr;
-  RtcGuard *d_guards = nullptr;  // reject-only box trees over the ROP_TRIS ranges (fast triangle kernel)
-  uint32_t n_guards = 0;
-  // per-scene scratch: [0] work counter (u32), [8..] 8 x u64 stats
-  unsigned char *d_scratch = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
-  uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_keys = nullptr, *d_tile_iota = nullptr;
-  void *d_sort_temp = nullptr;
-  size_t sort_temp_bytes = 0;
-  size_t lpt_pix = 0, lpt_tiles = 0;
-  // wavefront (v3) buffers: per-pixel state, ray and hit records, queues, control words
+#ifdef RL_EXPERIMENTAL
+struct ExpBuffers {  // wavefront (v3) buffers: per-pixel state, ray and hit records, queues, control words
   PixState *wf_pix = nullptr;
   RayRec *wf_ray = nullptr;
   HitRec *wf_hit = nullptr;
   uint32_t *wf_qtrav = nullptr, *wf_qshade = nullptr, *wf_qgen = nullptr, *wf_ctl = nullptr;
-  uint8_t *wf_class = nullptr;
   size_t wf_npix = 0;
 };
+#endif
 
 extern "C" {
 
@@ -137,24 +148,13 @@ int rl_abi_version(void) { return RL_ABI_VERSION; }
 const char *rl_last_error(void) { return g_err.c_str(); }
 
 int rl_init(int device) {
-  std::lock_guard<std::mutex> lk(g_mu);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return set_err(RL_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
-  if (device >= 0) {
-    if (device >= n) return set_err(RL_E_INVALID, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-  }
-  HIP_TRY(hipGetDevice(&g_device));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return set_err(RL_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
-  g_cus = prop.multiProcessorCount;
-  g_lds_max = prop.sharedMemPerBlock > 65536 ? prop.sharedMemPerBlock : 65536;
-  if (prop.maxSharedMemoryPerMultiProcessor > g_lds_max) g_lds_max = prop.maxSharedMemoryPerMultiProcessor;
-  if (g_lds_max > 163840) g_lds_max = 163840;
-  if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (device >= n) return set_err(RL_E_INVALID, "device index out of range");
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  int rc = rl::set_contexts({device});
+  if (rc != RL_OK) return rc;
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
     g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : 0;
@@ -166,15 +166,16 @@ int rl_init(int device) {
 
 void rl_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_stream) hipStreamDestroy(g_stream);
-  g_stream = nullptr;
+  for (DevCtx &c : g_ctx)
+    if (c.stream && hipSetDevice(c.device) == hipSuccess) hipStreamDestroy(c.stream), hipEventDestroy(c.ev);
+  g_ctx.clear();
   g_ready = false;
 }
 
 int rl_device_info(char *name, int cap) {
   if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+  HIP_TRY(hipGetDeviceProperties(&prop, g_ctx[0].device));
   if (name && cap > 0) {
     std::strncpy(name, prop.gcnArchName, (size_t)cap - 1);
     name[cap - 1] = 0;
@@ -182,17 +183,31 @@ int rl_device_info(char *name, int cap) {
   return prop.multiProcessorCount;
 }
 
-void rl_scene_destroy(rl_scene *s) {
-  if (!s) return;
+static void destroy_one(rl_scene *s) {
+  if ((size_t)s->ctx < g_ctx.size()) hipSetDevice(g_ctx[(size_t)s->ctx].device);
   hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_cops), hipFree(s->d_movbits), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards);
-  hipFree(s->wf_pix), hipFree(s->wf_ray), hipFree(s->wf_hit), hipFree(s->wf_qtrav), hipFree(s->wf_qshade), hipFree(s->wf_qgen), hipFree(s->wf_ctl), hipFree(s->wf_class);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays);
+#ifdef RL_EXPERIMENTAL
+  if (ExpBuffers *E = (ExpBuffers *)s->exp) {
+    hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
+    delete E;
+  }
+#endif
+  if (s->h_status) hipHostFree(s->h_status);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->ev_done) hipEventDestroy(s->ev_done);
   delete s;
+}
+
+void rl_scene_destroy(rl_scene *s) {
+  if (!s) return;
+  for (size_t g = 1; g < s->replicas.size(); g++) destroy_one(s->replicas[g]);
+  destroy_one(s);
+  if (!g_ctx.empty()) hipSetDevice(g_ctx[0].device);
 }
 
 static int scene_common(rl_scene *s) {
@@ -200,6 +215,9 @@ static int scene_common(rl_scene *s) {
   HIP_TRY(hipMemset(s->d_scratch, 0, 512));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc((void **)&s->h_status, 64, hipHostMallocDefault));
+  std::memset(s->h_status, 0, 64);
   return RL_OK;
 }
 
@@ -215,7 +233,46 @@ static int scene_common(rl_scene *s) {
 // A ray that certainly misses a sphere's box certainly misses the sphere, so the expensive binary64 Sphere::hit is skipped
 // for it (65 % of the leaf visits of BASELINE configs[1] end without a new closest hit).  Needs every sphere to be
 // referenced exactly once (*guards_ok = false otherwise).
-static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out, const rl_rtiow_scene_desc *guards = nullptr, bool *guards_ok = nullptr) {
+// Where the guard boxes' padding is valid.  A guard may only reject a ray that Sphere::hit (sphere.rs:32-75) would ALSO report as a
+// miss, and Sphere::hit decides on the sign of the ROUNDED discriminant half_b^2 - a*c.  For a ray whose line passes the centre at
+// distance b the exact value is a*(r^2 - b^2); the rounded one differs by at most ~16u*a*|oc|^2 (products and sums of the three
+// dot products) + 4u*a*M*|oc| (the rounding of oc = o - centre itself; M = largest coordinate involved), u = 2^-53.  A ray that
+// misses the box [c - r - pad, c + r + pad] has b >= r + pad, i.e. r^2 - b^2 <= -2*r*pad, so
+//     pad >= (8u*L^2 + 2u*M*L) / r      (L >= |oc|)
+// makes the rounded discriminant negative as well.  L and M follow from a FRAME: every ray origin the kernel ever uses is the
+// camera (checked against `reach` at render time, rtiow_render_launch) or a hit point on one of the scene's spheres.
+struct GuardFrame {
+  double center[3];  // centre of the scene's bounding box
+  double half;       // half of its diagonal
+  double reach;      // ray origins are within this distance of `center`
+  double M;          // bound on every coordinate magnitude of origins and centres
+};
+static GuardFrame guard_frame(const rl_rtiow_scene_desc &d) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = 0; i < d.n_spheres; i++) {
+    const rl_sphere &sp = d.spheres[i];
+    double r = std::fabs(sp.radius);
+    for (int ax = 0; ax < 3; ax++) {
+      double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
+      lo[ax] = std::fmin(lo[ax], std::fmin(c0, c1) - r), hi[ax] = std::fmax(hi[ax], std::fmax(c0, c1) + r);
+    }
+  }
+  GuardFrame f{};
+  double diag2 = 0.0, cmax = 0.0;
+  for (int ax = 0; ax < 3; ax++) {
+    if (!(lo[ax] <= hi[ax])) lo[ax] = hi[ax] = 0.0;  // no spheres (or NaN): an empty frame
+    f.center[ax] = 0.5 * (lo[ax] + hi[ax]);
+    diag2 += (hi[ax] - lo[ax]) * (hi[ax] - lo[ax]);
+    cmax = std::fmax(cmax, std::fmax(std::fabs(lo[ax]), std::fabs(hi[ax])));
+  }
+  f.half = 0.5 * std::sqrt(diag2);
+  f.reach = 4.0 * f.half + 1.0;  // a camera up to four scene radii away keeps the guards; farther away the render uses the unguarded ops
+  f.M = cmax + f.reach;
+  return f;
+}
+
+static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out, const rl_rtiow_scene_desc *guards = nullptr, bool *guards_ok = nullptr,
+                         const GuardFrame *frame = nullptr) {
   const uint32_t n0 = (uint32_t)ops.size();
   if (guards) {
     std::vector<uint8_t> seen(guards->n_spheres, 0);
@@ -272,7 +329,9 @@ static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out,
         for (int ax = 0; ax < 3; ax++) {
           double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
           double lo = std::fmin(c0, c1) - r, hi = std::fmax(c0, c1) + r;
-          double pad = 1e-9 * (std::fabs(lo) + std::fabs(hi) + r);  // this box only ever rejects: keep it comfortably outside the sphere
+          // this box only ever rejects: keep it outside the sphere by more than Sphere::hit's rounding can bridge (GuardFrame)
+          const double u = 1.1102230246251565e-16, L = frame ? frame->reach + frame->half : 0.0, M = frame ? frame->M : 0.0;
+          double pad = std::fmax(1e-9 * (std::fabs(lo) + std::fabs(hi) + r), 8.0 * (8.0 * u * L * L + 2.0 * u * M * L) / r);  // 8x the bound; r = 0: inf -> NaN box
           G.box[2 * ax] = lo - pad, G.box[2 * ax + 1] = hi + pad;
         }
         for (int ax = 0; ax < 6; ax++)
@@ -315,6 +374,56 @@ static void flatten_sphere_materials(const RtiowProgram &rt, std::vector<DevMate
   }
 }
 
+// Host half of rl_rtiow_scene_create: validate + lower the graph, link the ops, flatten the materials.  Device-independent.
+static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<const HostRtiow> &out) {
+  auto H = std::make_shared<HostRtiow>();
+  std::string err;
+  if (compile_rtiow(*desc, H->rt, err) != RL_OK) return set_err(RL_E_INVALID, err);
+  const RtiowProgram &rt = H->rt;
+  if (!(rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise) && rt.ops.size() < (1u << 29)) {
+    H->entry0 = link_ops(rt.ops, H->lops);
+    flatten_sphere_materials(rt, H->sphere_flat);
+    // compact guarded form (32-byte ops: binary32 box + the two successor words) for the 4-waves-per-SIMD layout
+    std::vector<DevOp> gops;
+    bool gok = false;
+    GuardFrame frame = guard_frame(*desc);
+    uint32_t gentry = link_ops(rt.ops, gops, desc, &gok, &frame);
+    if (gok && gops.size() < (1u << 24)) {
+      H->cops.resize(gops.size());
+      for (size_t i = 0; i < gops.size(); i++) {
+        for (int k = 0; k < 6; k++) H->cops[i].box[k] = (float)gops[i].box[k];
+        H->cops[i].w_hit = gops[i].code, H->cops[i].w_miss = gops[i].skip;
+      }
+      H->movbits.assign((rt.spheres.size() + 31) / 32 + 1, 0u);
+      for (size_t i = 0; i < rt.spheres.size(); i++)
+        if (desc->spheres[i].moving) H->movbits[i >> 5] |= 1u << (i & 31);
+      H->centry0 = gentry;
+      std::memcpy(H->guard_center, frame.center, sizeof frame.center);
+      H->guard_reach = frame.reach;
+    }
+  }
+  out = H;
+  return RL_OK;
+}
+
+// Device half: one replica on device context `ctx` (the current device must already be that context's)
+static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx) {
+  rl_scene *s = new rl_scene();
+  s->kind = 1, s->ctx = ctx, s->hrt = H;
+  const RtiowProgram &rt = H->rt;
+  int rc = RL_OK;
+  if ((rc = upload(rt.ops, &s->d_ops)) || (rc = upload(rt.spheres, &s->d_spheres)) || (rc = upload(rt.sphere_material, &s->d_sphere_material)) ||
+      (rc = upload(rt.planars, &s->d_planars)) || (rc = upload(rt.translates, &s->d_translates)) || (rc = upload(rt.transforms, &s->d_transforms)) ||
+      (rc = upload(rt.materials, &s->d_materials)) || (rc = upload(rt.textures, &s->d_textures)) || (rc = upload(rt.images, &s->d_images)) ||
+      (rc = upload(rt.image_pool, &s->d_image_pool)) || (rc = upload(rt.perlins, &s->d_perlins)) || (rc = scene_common(s)) ||
+      (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
+      (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits))))) {
+    destroy_one(s);
+    return nullptr;
+  }
+  return s;
+}
+
 rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
   if (!g_ready) {
     set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
@@ -324,52 +433,22 @@ rl_scene *rl_rtiow_scene_create(const rl_rtiow_scene_desc *desc) {
     set_err(RL_E_INVALID, "null scene descriptor");
     return nullptr;
   }
-  rl_scene *s = new rl_scene();
-  s->kind = 1;
-  std::string err;
-  if (compile_rtiow(*desc, s->rt, err) != RL_OK) {
-    set_err(RL_E_INVALID, err);
-    delete s;
-    return nullptr;
-  }
-  int rc = RL_OK;
-  if ((rc = upload(s->rt.ops, &s->d_ops)) || (rc = upload(s->rt.spheres, &s->d_spheres)) || (rc = upload(s->rt.sphere_material, &s->d_sphere_material)) ||
-      (rc = upload(s->rt.planars, &s->d_planars)) || (rc = upload(s->rt.translates, &s->d_translates)) || (rc = upload(s->rt.transforms, &s->d_transforms)) ||
-      (rc = upload(s->rt.materials, &s->d_materials)) || (rc = upload(s->rt.textures, &s->d_textures)) || (rc = upload(s->rt.images, &s->d_images)) ||
-      (rc = upload(s->rt.image_pool, &s->d_image_pool)) || (rc = upload(s->rt.perlins, &s->d_perlins)) || (rc = scene_common(s))) {
-    rl_scene_destroy(s);
-    return nullptr;
-  }
-  if (!(s->rt.has_planars || s->rt.has_instances || s->rt.has_images || s->rt.has_noise) && s->rt.ops.size() < (1u << 29)) {
-    std::vector<DevOp> lops;
-    s->entry0 = link_ops(s->rt.ops, lops);
-    std::vector<DevMaterial> flat;
-    flatten_sphere_materials(s->rt, flat);
-    if (upload(lops, &s->d_lops) != RL_OK || upload(flat, &s->d_sphere_flat) != RL_OK) {
-      rl_scene_destroy(s);
+  std::shared_ptr<const HostRtiow> H;
+  if (build_host_rtiow(desc, H) != RL_OK) return nullptr;
+  // one replica per device context (rl_init: one; rl_init_multi: one per GPU — the scene is replicated)
+  std::vector<rl_scene *> reps;
+  for (int g = 0; g < (int)g_ctx.size(); g++) {
+    rl_scene *r = rl::use_context(g) == RL_OK ? upload_rtiow(H, g) : nullptr;
+    if (!r) {
+      for (rl_scene *q : reps) destroy_one(q);
+      hipSetDevice(g_ctx[0].device);
       return nullptr;
     }
-    // compact guarded form (32-byte ops: binary32 box + the two successor words) for the 4-waves-per-SIMD layout
-    std::vector<DevOp> gops;
-    bool gok = false;
-    uint32_t gentry = link_ops(s->rt.ops, gops, desc, &gok);
-    if (gok && gops.size() < (1u << 24)) {
-      std::vector<CompactOp> cops(gops.size());
-      for (size_t i = 0; i < gops.size(); i++) {
-        for (int k = 0; k < 6; k++) cops[i].box[k] = (float)gops[i].box[k];
-        cops[i].w_hit = gops[i].code, cops[i].w_miss = gops[i].skip;
-      }
-      std::vector<uint32_t> movbits((s->rt.spheres.size() + 31) / 32 + 1, 0u);
-      for (size_t i = 0; i < s->rt.spheres.size(); i++)
-        if (desc->spheres[i].moving) movbits[i >> 5] |= 1u << (i & 31);
-      if (upload(cops, &s->d_cops) != RL_OK || upload(movbits, &s->d_movbits) != RL_OK) {
-        rl_scene_destroy(s);
-        return nullptr;
-      }
-      s->n_cops = (uint32_t)cops.size(), s->centry0 = gentry;
-    }
+    reps.push_back(r);
   }
-  return s;
+  hipSetDevice(g_ctx[0].device);
+  if (reps.size() > 1) reps[0]->replicas = reps;
+  return reps[0];
 }
 
 // ChaCha8Rng::seed_from_u64 (rand_core 0.6.4): PCG32 expands the u64 into the 256-bit key
@@ -389,10 +468,38 @@ static void read_stats(const unsigned long long *h, float ms, rl_stats *st) {
   st->kernel_ms = ms;
 }
 
+}  // extern "C"
+
+namespace rl {
+// counting renders: ev0 / ev1 bracket the kernels on `stream`; the stats words are read back synchronously
+int collect_stats(const rl_scene *scene, hipStream_t stream, rl_stats *st) {
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpyAsync(h, scene->d_scratch + 64, sizeof h, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
+  read_stats(h, ms, st);
+  if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
+  return RL_OK;
+}
+}  // namespace rl
+
+// asynchronous renders: leave the stats words in pinned host memory behind an event (rl_render_status reads them)
+static int post_status(const rl_scene *scene, hipStream_t stream) {
+  rl_scene *ms = const_cast<rl_scene *>(scene);
+  HIP_TRY(hipMemcpyAsync(ms->h_status, scene->d_scratch + 64, 64, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(ms->ev_done, stream));
+  ms->async_pending = true;
+  return RL_OK;
+}
+
+#ifdef RL_EXPERIMENTAL
 // Wavefront (v3) driver: one PASS = begin_pass, TRAV, SHADE, GEN (rl_rtiow_wavefront.h); passes are enqueued in
 // chunks and the finished-pixel counter is polled once per chunk.
 static int render_wavefront(const rl_scene *scene, RtiowParams &P, uint32_t nrows, hipStream_t stream, bool want_stats) {
-  rl_scene *ms = const_cast<rl_scene *>(scene);  // work buffers only; the scene program is immutable
+  rl_scene *sc = const_cast<rl_scene *>(scene);  // work buffers only; the scene program is immutable
+  if (!sc->exp) sc->exp = new ExpBuffers();
+  ExpBuffers *ms = (ExpBuffers *)sc->exp;
   const uint32_t Wd = P.cam.image_width;
   size_t npix = (size_t)nrows * Wd;
   if (npix >= 0xFFFF0000ull) return set_err(RL_E_INVALID, "image too large");
@@ -467,25 +574,23 @@ static int render_wavefront(const rl_scene *scene, RtiowParams &P, uint32_t nrow
   return RL_OK;
 }
 
-int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step,
-                           void *d_out, void *hip_stream, rl_stats *st) {
-  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
-  if (!scene || scene->kind != 1 || !cam || !d_out || row_step == 0) return set_err(RL_E_INVALID, "bad argument");
-  if (cam->image_width == 0 || cam->image_height == 0) return set_err(RL_E_INVALID, "empty image");
-  hipStream_t stream = (hipStream_t)hip_stream;
-  uint32_t H = cam->image_height, W = cam->image_width;
-  uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
-  if (nrows == 0) {
-    if (st) std::memset(st, 0, sizeof *st);
-    return RL_OK;
-  }
+#endif
+
+namespace rl {
+int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, void *d_out,
+                        hipStream_t stream, bool want_stats) {
+  const RtiowProgram &rt = scene->rt();
+  const HostRtiow &H = *scene->hrt;
+  uint32_t H_ = cam->image_height, W = cam->image_width;
+  uint32_t nrows = row_first < H_ ? (H_ - row_first + row_step - 1) / row_step : 0;
   RtiowParams P{};
   P.ops = scene->d_ops, P.spheres = scene->d_spheres, P.sphere_material = scene->d_sphere_material;
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
   P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins;
-  P.n_ops = (uint32_t)scene->rt.ops.size(), P.n_spheres = (uint32_t)scene->rt.spheres.size();
-  P.lops = scene->d_lops, P.entry0 = scene->entry0, P.sphere_flat = scene->d_sphere_flat;
-  P.cops = scene->d_cops, P.n_cops = scene->n_cops, P.centry0 = scene->centry0, P.movbits = scene->d_movbits;
+  P.n_ops = (uint32_t)rt.ops.size(), P.n_spheres = (uint32_t)rt.spheres.size();
+  P.lops = scene->d_lops, P.entry0 = H.entry0, P.sphere_flat = scene->d_sphere_flat;
+  const uint32_t n_cops = (uint32_t)H.cops.size();
+  P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;
@@ -506,10 +611,10 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     if (nf >= 3) P.tune[2] = c;
     if (nf >= 4) P.tune[3] = d;
   }
+  P.pix_rays = want_stats ? scene->d_pix_rays : nullptr;
 
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
-  bool want_stats = st != nullptr;
   auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
     size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
     uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
@@ -529,11 +634,26 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
-  bool general = scene->rt.has_planars || scene->rt.has_instances || scene->rt.has_images || scene->rt.has_noise;
+  bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise;
+#ifndef RL_EXPERIMENTAL
+  if (variant == 3 || variant == 5 || variant == 6 || variant == 7) return set_err(RL_E_UNSUPPORTED, "experimental kernel variants live in librl_render_exp.so only");
+#endif
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
-  const size_t compact_bytes = ((size_t)scene->n_cops * sizeof(CompactOp) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const bool fits_compact = scene->n_cops != 0 && (size_t)16 * 1024 * sizeof(unsigned long long) + compact_bytes <= g_lds_max;
+  const size_t compact_bytes = ((size_t)n_cops * sizeof(CompactOp) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  bool fits_compact = n_cops != 0 && (size_t)16 * 1024 * sizeof(unsigned long long) + compact_bytes <= g_lds_max;
+  if (fits_compact) {
+    // the guard boxes' padding covers the rounding of Sphere::hit only for ray origins within guard_reach of the scene
+    // (link_ops); every later origin is a hit point inside the scene, so only the camera has to be checked
+    double far = 0.0;
+    for (int k = 0; k < 3; k++) {
+      double c = cam->lookfrom[k] - H.guard_center[k];
+      far += c * c;
+    }
+    double disk = 0.0;
+    for (int k = 0; k < 3; k++) disk += std::fabs(cam->defocus_disk_u[k]) + std::fabs(cam->defocus_disk_v[k]);
+    if (!(std::sqrt(far) + disk <= H.guard_reach)) fits_compact = false;  // also for NaN
+  }
   if (variant == 1027 && (general || !fits_compact)) variant = 0;
   if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
@@ -562,7 +682,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of
       // scenes that have Noise textures or Image textures on spheres).  At 768 lanes (168 VGPRs) the spills land in the TRAV
       // loop and cost 2.3x (measured, cfg 4: 1101 vs 465 Mrays/s).  RL_GENERAL_NT=768 overrides (A/B only).
-      bool trans = scene->rt.has_noise || scene->rt.has_sphere_uv;
+      bool trans = rt.has_noise || rt.has_sphere_uv;
       int gnt = 512;
       if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);
       size_t rb = (size_t)16 * gnt * sizeof(unsigned long long);
@@ -570,6 +690,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
       else if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, true, false>, 512, rb, false);
       else if (gnt == 512) rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, false, false>, 512, rb, false);
       else rc = want_stats ? launch(rtiow_wave_general_kernel<768, false, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, false, false>, 768, rb, false);
+#ifdef RL_EXPERIMENTAL
     } else if (variant == 5) {
       constexpr int NT = 512;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
@@ -580,6 +701,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     } else if (variant == 6) {
       constexpr int NT = 256;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
+#endif
     } else if (variant == 1) {
       constexpr int NT = 1024;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
@@ -610,11 +732,13 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
   bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
-  if (variant == 3) P.sample_begin = 0, P.sample_end = cam->samples_per_pixel;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;
-  if (variant == 3) rc = render_wavefront(scene, P, nrows, stream, want_stats);
-  else if (!lpt) rc = launch_variant();
+  if (variant == 3) {
+#ifdef RL_EXPERIMENTAL
+    rc = render_wavefront(scene, P, nrows, stream, want_stats);
+#endif
+  } else if (!lpt) rc = launch_variant();
   else {
     rl_scene *ms = const_cast<rl_scene *>(scene);  // scratch buffers only; the scene program itself is immutable
     size_t npix = (size_t)nrows * W, ntiles = (size_t)(slots >> 6);
@@ -647,27 +771,85 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     rc = launch_variant();
   }
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
-  if (rc != RL_OK) return rc;
-  if (want_stats) {
-    unsigned long long h[8];
-    HIP_TRY(hipMemcpyAsync(h, P.stats, sizeof h, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
-    read_stats(h, ms, st);
-    if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
+  return rc;
+}
+}  // namespace rl
+
+extern "C" {
+
+int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step,
+                           void *d_out, void *hip_stream, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || scene->kind != 1 || !cam || !d_out || row_step == 0) return set_err(RL_E_INVALID, "bad argument");
+  if (cam->image_width == 0 || cam->image_height == 0) return set_err(RL_E_INVALID, "empty image");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (row_first >= cam->image_height) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
   }
+  int rc = rl::rtiow_render_launch(scene, cam, first_sample, row_first, row_step, d_out, stream, st != nullptr);
+  if (rc != RL_OK) return rc;
+  return st ? rl::collect_stats(scene, stream, st) : post_status(scene, stream);
+}
+
+// Completion + status of the last ASYNCHRONOUS render of this scene (rl_*_render_device / rl_*_render_multi_device with
+// opt_stats == NULL): waits for it, fills rays and flagged (the other counters need a counting render) and returns
+// RL_E_DEGENERATE when a reference panic site was reached.  RL_OK with zero counters when nothing is pending.
+int rl_render_status(const rl_scene *scene, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene) return set_err(RL_E_INVALID, "bad argument");
+  rl_stats acc;
+  std::memset(&acc, 0, sizeof acc);
+  size_t n = scene->replicas.empty() ? 1 : scene->replicas.size();
+  for (size_t g = 0; g < n; g++) {
+    rl_scene *r = const_cast<rl_scene *>(scene->replicas.empty() ? scene : scene->replicas[g]);
+    if (!r->async_pending) continue;
+    int rc = rl::use_context(r->ctx);
+    if (rc != RL_OK) return rc;
+    HIP_TRY(hipEventSynchronize(r->ev_done));
+    r->async_pending = false;
+    acc.rays += r->h_status[0], acc.flagged += r->h_status[6];
+  }
+  if (n > 1) rl::use_context(0);
+  if (st) *st = acc;
+  if (acc.flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
   return RL_OK;
 }
 
 // Not part of the ABI (tests / tools only): force an RTIOW kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave).
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
+int rl_debug_has_experimental(void) {
+#ifdef RL_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // Not part of the ABI (tools only): scheduler occupancy counters of the last STATS launch, 32 x u64.
 int rl_debug_sched(const rl_scene *scene, unsigned long long *out32) {
   if (!scene || !out32) return RL_E_INVALID;
   HIP_TRY(hipMemcpy(out32, scene->d_scratch + 128, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RL_OK;
+}
+
+// Not part of the ABI (tools only): per-pixel ray counts of the NEXT counting renders of this scene, n_pixels u32 (rows x W of
+// the shard rendered); rl_debug_pixel_rays_read copies them back.  Pass 0 to switch the recording off.
+int rl_debug_pixel_rays(const rl_scene *scene, uint64_t n_pixels) {
+  if (!scene) return RL_E_INVALID;
+  rl_scene *ms = const_cast<rl_scene *>(scene);
+  hipFree(ms->d_pix_rays);
+  ms->d_pix_rays = nullptr;
+  if (n_pixels) {
+    HIP_TRY(hipMalloc((void **)&ms->d_pix_rays, n_pixels * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ms->d_pix_rays, 0, n_pixels * sizeof(uint32_t)));
+  }
+  return RL_OK;
+}
+int rl_debug_pixel_rays_read(const rl_scene *scene, uint32_t *out, uint64_t n_pixels) {
+  if (!scene || !scene->d_pix_rays || !out) return RL_E_INVALID;
+  HIP_TRY(hipMemcpy(out, scene->d_pix_rays, n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return RL_OK;
 }
 
@@ -682,10 +864,12 @@ int rl_rtiow_render_rows(const rl_scene *scene, const rl_rtiow_camera *cam, uint
     if (st) std::memset(st, 0, sizeof *st);
     return RL_OK;
   }
+  int rc0 = rl::use_context(scene->ctx);
+  if (rc0 != RL_OK) return rc0;
   double *d_out = nullptr;
   HIP_TRY(hipMalloc((void **)&d_out, bytes));
   rl_stats local;
-  int rc = rl_rtiow_render_device(scene, cam, first_sample, row_first, row_step, d_out, g_stream, &local);
+  int rc = rl_rtiow_render_device(scene, cam, first_sample, row_first, row_step, d_out, g_ctx[(size_t)scene->ctx].stream, &local);
   if (rc == RL_OK || rc == RL_E_DEGENERATE) {
     hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
@@ -711,6 +895,9 @@ int rl_rtiow_render_rgb8(const rl_scene *scene, const rl_rtiow_camera *cam, uint
   if (!scene || !cam || !out) return set_err(RL_E_INVALID, "bad argument");
   size_t npix = (size_t)cam->image_width * cam->image_height;
   if (npix == 0 || cam->samples_per_pixel == 0) return set_err(RL_E_INVALID, "empty image / zero samples");
+  int rc0 = rl::use_context(scene->ctx);
+  if (rc0 != RL_OK) return rc0;
+  hipStream_t stream = g_ctx[(size_t)scene->ctx].stream;
   double *d_sum = nullptr;
   unsigned char *d_u8 = nullptr;
   HIP_TRY(hipMalloc((void **)&d_sum, npix * 3 * sizeof(double)));
@@ -720,13 +907,13 @@ int rl_rtiow_render_rgb8(const rl_scene *scene, const rl_rtiow_camera *cam, uint
     return set_err(RL_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
   rl_stats local;
-  int rc = rl_rtiow_render_device(scene, cam, first_sample, 0, 1, d_sum, g_stream, &local);
+  int rc = rl_rtiow_render_device(scene, cam, first_sample, 0, 1, d_sum, stream, &local);
   if (rc == RL_OK || rc == RL_E_DEGENERATE) {
-    int rc2 = rl_rtiow_encode_rgb8_device(d_sum, npix, cam->samples_per_pixel, d_u8, g_stream);
+    int rc2 = rl_rtiow_encode_rgb8_device(d_sum, npix, cam->samples_per_pixel, d_u8, stream);
     if (rc2 != RL_OK) rc = rc2;
     else {
-      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, g_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
       if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("D2H: ") + hipGetErrorString(e));
     }
   }
@@ -791,6 +978,20 @@ static void build_rtc_guards(RtcProgram &rc, std::vector<RtcGuard> &guards) {
     }
 }
 
+static rl_scene *upload_rtc(const std::shared_ptr<const HostRtc> &H, int ctx) {
+  rl_scene *s = new rl_scene();
+  s->kind = 2, s->ctx = ctx, s->hrc = H;
+  const RtcProgram &rc_ = H->rc;
+  int rc = RL_OK;
+  if ((!H->guards.empty() && (rc = upload(H->guards, &s->d_guards))) || (rc = upload(rc_.ops, &s->d_ops)) || (rc = upload(rc_.tris, &s->d_tris)) ||
+      (rc = upload(rc_.xforms, &s->d_xforms)) || (rc = upload(rc_.materials, &s->d_rmaterials)) || (rc = upload(rc_.lights, &s->d_lights)) ||
+      (rc = upload(rc_.shapes, &s->d_shapes)) || (rc = upload(rc_.csgs, &s->d_csgs)) || (rc = upload(rc_.patterns, &s->d_patterns)) || (rc = scene_common(s))) {
+    destroy_one(s);
+    return nullptr;
+  }
+  return s;
+}
+
 rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
   if (!g_ready) {
     set_err(RL_E_NO_DEVICE, "rl_init has not succeeded (no GPU, or not called)");
@@ -800,57 +1001,57 @@ rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
     set_err(RL_E_INVALID, "null scene descriptor");
     return nullptr;
   }
-  rl_scene *s = new rl_scene();
-  s->kind = 2;
+  auto H = std::make_shared<HostRtc>();
   std::string err;
-  if (compile_rtc(*desc, s->rc, err) != RL_OK) {
+  if (compile_rtc(*desc, H->rc, err) != RL_OK) {
     set_err(RL_E_INVALID, err);
-    delete s;
     return nullptr;
   }
-  if (s->rc.lights.size() > 0xFFFFu) {
+  if (H->rc.lights.size() > 0xFFFFu) {
     set_err(RL_E_UNSUPPORTED, "too many lights");
-    delete s;
     return nullptr;
   }
-  int rc = RL_OK;
-  std::vector<RtcGuard> guards;
-  if (!s->rc.needs_full) build_rtc_guards(s->rc, guards);
-  s->n_guards = (uint32_t)guards.size();
-  if (!guards.empty() && upload(guards, &s->d_guards) != RL_OK) {
-    rl_scene_destroy(s);
+  // rtc_full_kernel walks the reflection / refraction tree with a fixed stack of pending rays (RTC_MAX_PENDING): a material that is
+  // both reflective and transparent keeps up to max_reflection_depth + 1 of them alive (world.rs:128-159 recurses without a cap)
+  if (H->rc.needs_full && H->rc.max_reflection_depth + 1u > RTC_MAX_PENDING) {
+    set_err(RL_E_UNSUPPORTED, "max_reflection_depth above " + std::to_string(RTC_MAX_PENDING - 1) + " is not supported by the device kernel");
     return nullptr;
   }
-  if ((rc = upload(s->rc.ops, &s->d_ops)) || (rc = upload(s->rc.tris, &s->d_tris)) || (rc = upload(s->rc.xforms, &s->d_xforms)) ||
-      (rc = upload(s->rc.materials, &s->d_rmaterials)) || (rc = upload(s->rc.lights, &s->d_lights)) || (rc = upload(s->rc.shapes, &s->d_shapes)) ||
-      (rc = upload(s->rc.csgs, &s->d_csgs)) || (rc = upload(s->rc.patterns, &s->d_patterns)) || (rc = scene_common(s))) {
-    rl_scene_destroy(s);
-    return nullptr;
+  if (!H->rc.needs_full) build_rtc_guards(H->rc, H->guards);
+  std::shared_ptr<const HostRtc> Hc = H;
+  std::vector<rl_scene *> reps;
+  for (int g = 0; g < (int)g_ctx.size(); g++) {
+    rl_scene *r = rl::use_context(g) == RL_OK ? upload_rtc(Hc, g) : nullptr;
+    if (!r) {
+      for (rl_scene *q : reps) destroy_one(q);
+      hipSetDevice(g_ctx[0].device);
+      return nullptr;
+    }
+    reps.push_back(r);
   }
-  return s;
+  hipSetDevice(g_ctx[0].device);
+  if (reps.size() > 1) reps[0]->replicas = reps;
+  return reps[0];
 }
 
-int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out,
-                         void *hip_stream, rl_stats *st) {
-  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
-  if (!scene || scene->kind != 2 || !cam || !d_out || row_step == 0 || aa == 0) return set_err(RL_E_INVALID, "bad argument");
-  if (cam->hsize == 0 || cam->vsize == 0) return set_err(RL_E_INVALID, "empty image");
-  hipStream_t stream = (hipStream_t)hip_stream;
+}  // extern "C"
+
+namespace rl {
+int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out, hipStream_t stream,
+                      bool want_stats) {
+  const RtcProgram &rc_ = scene->rc();
   uint32_t H = cam->vsize, W = cam->hsize;
   uint32_t nrows = row_first < H ? (H - row_first + row_step - 1) / row_step : 0;
-  if (nrows == 0) {
-    if (st) std::memset(st, 0, sizeof *st);
-    return RL_OK;
-  }
+  const uint32_t n_guards = (uint32_t)scene->hrc->guards.size();
   RtcParams P{};
   P.ops = scene->d_ops, P.tris = scene->d_tris, P.xforms = scene->d_xforms, P.materials = scene->d_rmaterials, P.lights = scene->d_lights;
-  P.n_ops = (uint32_t)scene->rc.ops.size(), P.n_tris = (uint32_t)scene->rc.tris.size();
-  P.guards = scene->n_guards ? scene->d_guards : nullptr, P.n_guards = scene->n_guards;
-  P.n_xforms = (uint32_t)scene->rc.xforms.size(), P.n_lights = (uint32_t)scene->rc.lights.size();
+  P.n_ops = (uint32_t)rc_.ops.size(), P.n_tris = (uint32_t)rc_.tris.size();
+  P.guards = n_guards ? scene->d_guards : nullptr, P.n_guards = n_guards;
+  P.n_xforms = (uint32_t)rc_.xforms.size(), P.n_lights = (uint32_t)rc_.lights.size();
   P.cam = *cam;
   P.aa = aa;
   P.row_first = row_first, P.row_step = row_step, P.nrows = nrows;
-  std::memcpy(P.void_color, scene->rc.void_color, 24);
+  std::memcpy(P.void_color, rc_.void_color, 24);
   P.out = (double *)d_out;
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
@@ -861,28 +1062,36 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
   uint64_t total = (uint64_t)W * nrows;
   uint64_t want = (total + NT - 1) / NT;
   uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
-  bool want_stats = st != nullptr;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
-  if (scene->rc.needs_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
+  if (rc_.needs_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
     RtcFullParams F{};
     F.R = P;
     F.shapes = scene->d_shapes, F.csgs = scene->d_csgs, F.patterns = scene->d_patterns;
-    F.n_tris = P.n_tris, F.max_reflection_depth = scene->rc.max_reflection_depth;
+    F.n_tris = P.n_tris, F.max_reflection_depth = rc_.max_reflection_depth;
     hipLaunchKernelGGL((rtc_full_kernel<NT>), dim3(blocks), dim3(NT), 0, stream, F);
   } else if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
   else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
   HIP_TRY(hipGetLastError());
-  if (want_stats) {
-    HIP_TRY(hipEventRecord(scene->ev1, stream));
-    unsigned long long h[8];
-    HIP_TRY(hipMemcpyAsync(h, P.stats, sizeof h, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, scene->ev0, scene->ev1));
-    read_stats(h, ms, st);
-    if (st->flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
-  }
+  if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
   return RL_OK;
+}
+}  // namespace rl
+
+extern "C" {
+
+int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out,
+                         void *hip_stream, rl_stats *st) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || scene->kind != 2 || !cam || !d_out || row_step == 0 || aa == 0) return set_err(RL_E_INVALID, "bad argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return set_err(RL_E_INVALID, "empty image");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (row_first >= cam->vsize) {
+    if (st) std::memset(st, 0, sizeof *st);
+    return RL_OK;
+  }
+  int rc = rl::rtc_render_launch(scene, cam, aa, row_first, row_step, d_out, stream, st != nullptr);
+  if (rc != RL_OK) return rc;
+  return st ? rl::collect_stats(scene, stream, st) : post_status(scene, stream);
 }
 
 int rl_rtc_render_rows(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, double *out,
@@ -896,10 +1105,12 @@ int rl_rtc_render_rows(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t
     if (st) std::memset(st, 0, sizeof *st);
     return RL_OK;
   }
+  int rc0 = rl::use_context(scene->ctx);
+  if (rc0 != RL_OK) return rc0;
   double *d_out = nullptr;
   HIP_TRY(hipMalloc((void **)&d_out, bytes));
   rl_stats local;
-  int rc = rl_rtc_render_device(scene, cam, aa, row_first, row_step, d_out, g_stream, &local);
+  int rc = rl_rtc_render_device(scene, cam, aa, row_first, row_step, d_out, g_ctx[(size_t)scene->ctx].stream, &local);
   if (rc == RL_OK || rc == RL_E_DEGENERATE) {
     hipError_t e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
@@ -924,6 +1135,9 @@ int rl_rtc_render_rgb8(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t
   if (!scene || !cam || !out) return set_err(RL_E_INVALID, "bad argument");
   size_t npix = (size_t)cam->hsize * cam->vsize;
   if (npix == 0) return set_err(RL_E_INVALID, "empty image");
+  int rc0 = rl::use_context(scene->ctx);
+  if (rc0 != RL_OK) return rc0;
+  hipStream_t stream = g_ctx[(size_t)scene->ctx].stream;
   double *d_rgb = nullptr;
   unsigned char *d_u8 = nullptr;
   HIP_TRY(hipMalloc((void **)&d_rgb, npix * 3 * sizeof(double)));
@@ -933,13 +1147,13 @@ int rl_rtc_render_rgb8(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t
     return set_err(RL_E_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
   rl_stats local;
-  int rc = rl_rtc_render_device(scene, cam, aa, 0, 1, d_rgb, g_stream, &local);
+  int rc = rl_rtc_render_device(scene, cam, aa, 0, 1, d_rgb, stream, &local);
   if (rc == RL_OK || rc == RL_E_DEGENERATE) {
-    int rc2 = rl_rtc_encode_rgb8_device(d_rgb, npix, d_u8, g_stream);
+    int rc2 = rl_rtc_encode_rgb8_device(d_rgb, npix, d_u8, stream);
     if (rc2 != RL_OK) rc = rc2;
     else {
-      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, g_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+      e = hipMemcpyAsync(out, d_u8, npix * 3, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
       if (e != hipSuccess) rc = set_err(RL_E_DEVICE, std::string("D2H: ") + hipGetErrorString(e));
     }
   }

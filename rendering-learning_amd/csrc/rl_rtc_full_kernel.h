@@ -327,11 +327,15 @@ __device__ __forceinline__ bool rtc_are_equal(double a, double b) {  // math/uti
   return diff <= 8;
 }
 
+// Pending reflection / refraction rays of one camera ray, walked depth-first: a ray with `remaining` bounces left pushes at most
+// two rays with remaining - 1, so max_reflection_depth + 1 slots are enough (rl_rtc_scene_create rejects deeper worlds with
+// RL_E_UNSUPPORTED; the reference recurses without a cap, world.rs:128-159).
+static const uint32_t RTC_MAX_PENDING = 8;
 struct Pending {
   D3 o, d;
   double w;
   uint32_t remaining;
-  uint32_t mult;  // how many times the reference evaluates this ray (it recomputes reflected / refracted per light)
+  unsigned long long mult;  // how many times the reference evaluates this ray (it recomputes reflected / refracted per light)
 };
 
 template <int NT>
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
   RtcFullCounters cnt{0, 0, 0, 0, 0, 0};
   const uint64_t total = (uint64_t)W * P.nrows;
   Ent list[RL_RTC_K];
-  Pending stack[8];
+  Pending stack[RTC_MAX_PENDING];
   for (uint64_t idx = (uint64_t)blockIdx.x * NT + tid; idx < total; idx += (uint64_t)gridDim.x * NT) {
     uint32_t r = (uint32_t)(idx / W), px = (uint32_t)(idx % W);
     uint32_t py = P.row_first + r * P.row_step;
@@ -365,7 +369,7 @@ __global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
         }
         D3 c = d3(0.0, 0.0, 0.0);
         int sp = 0;
-        stack[sp++] = Pending{origin, dir, 1.0, F.max_reflection_depth, 1u};
+        stack[sp++] = Pending{origin, dir, 1.0, F.max_reflection_depth, 1ull};
         while (sp > 0) {
           Pending cur = stack[--sp];
           cnt.rays += cur.mult;
@@ -486,14 +490,16 @@ __global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
             double n_ratio = n1 / n2;
             double cos_i = dot(eye_v, normal_v);
             double sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
-            if (!(sin2_t > 1.0) && sp < 8) {
+            if (!(sin2_t > 1.0) && sp >= (int)RTC_MAX_PENDING) cnt.flagged++;  // cannot happen for a world rl_rtc_scene_create accepted
+            else if (!(sin2_t > 1.0)) {
               double cos_t = sqrt(1.0 - sin2_t);
               D3 direction = normal_v * (n_ratio * cos_i - cos_t) - eye_v * n_ratio;
               double wt = wl * m.transparency * (both ? (1.0 - reflectance) : 1.0);
               stack[sp++] = Pending{under_point, direction, wt, cur.remaining - 1, cur.mult * P.n_lights};
             }
           }
-          if (cur.remaining > 0 && m.reflectivity != 0.0 && sp < 8) {
+          if (cur.remaining > 0 && m.reflectivity != 0.0 && sp >= (int)RTC_MAX_PENDING) cnt.flagged++;
+          else if (cur.remaining > 0 && m.reflectivity != 0.0) {
             double wr = wl * m.reflectivity * (both ? reflectance : 1.0);
             stack[sp++] = Pending{over_point, reflect_v, wr, cur.remaining - 1, cur.mult * P.n_lights};
           }

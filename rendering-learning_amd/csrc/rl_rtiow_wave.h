@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             if (P.pos_state) P.pos_state[pix] = rng.pos;               // resumable: the next launch continues this pixel
             if (P.tile_cost) atomicAdd(&P.tile_cost[ptile], pix_rays);  // cost estimate for the LPT order of the next launch
             if (STATS && !P.tile_cost) c_words += rng.pos;
+            if (STATS && P.pix_rays) P.pix_rays[pix] += pix_rays;
             have_pixel = false;
           }
           uint32_t slot = wave_claim(P.work_counter);

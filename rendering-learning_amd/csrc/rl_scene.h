@@ -1,0 +1,109 @@
+// Internal (not part of the ABI): the library's per-device context and the rl_scene object, shared by rl_render.hip (the
+// single-device entry points) and rl_multi.hip (one process driving several GPUs).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rl_program.h"
+
+namespace rl {
+
+// One per GPU the library drives.  rl_init(device) creates exactly one; rl_init_multi(n) one per device 0 .. n-1.
+struct DevCtx {
+  int device = -1;        // HIP device ordinal
+  hipStream_t stream = nullptr;  // library-owned stream (host-buffer entry points, multi-GPU renders)
+  hipEvent_t ev = nullptr;       // "this device's shard has arrived" (peer-copy gather)
+};
+
+// What the host side of a scene compiles to; immutable, shared by the per-device replicas of one scene.
+struct HostRtiow {
+  RtiowProgram rt;
+  std::vector<DevOp> lops;  // linked ops (sphere-only scenes)
+  std::vector<DevMaterial> sphere_flat;
+  std::vector<CompactOp> cops;  // guarded compact ops
+  std::vector<uint32_t> movbits;
+  uint32_t entry0 = 0, centry0 = 0;
+  // the guard boxes' padding is rigorous for ray origins within guard_reach of guard_center (rl_render.hip link_ops)
+  double guard_center[3] = {0, 0, 0}, guard_reach = 0;
+};
+struct HostRtc {
+  RtcProgram rc;
+  std::vector<RtcGuard> guards;
+};
+
+}  // namespace rl
+
+struct rl_scene {
+  int kind = 0;  // 1 = RTIOW, 2 = RTC
+  int ctx = 0;   // index of the device context this replica lives on
+  std::shared_ptr<const rl::HostRtiow> hrt;
+  std::shared_ptr<const rl::HostRtc> hrc;
+  const rl::RtiowProgram &rt() const { return hrt->rt; }
+  const rl::RtcProgram &rc() const { return hrc->rc; }
+  std::vector<rl_scene *> replicas;  // multi-GPU: replicas[g] lives on device context g; replicas[0] == this (empty: single device)
+  // RTIOW
+  rl::DevOp *d_ops = nullptr;
+  rl::DevOp *d_lops = nullptr;
+  rl::DevMaterial *d_sphere_flat = nullptr;
+  rl::CompactOp *d_cops = nullptr;
+  uint32_t *d_movbits = nullptr;
+  rl::DevSphere *d_spheres = nullptr;
+  uint32_t *d_sphere_material = nullptr;
+  rl::DevPlanar *d_planars = nullptr;
+  rl_translate *d_translates = nullptr;
+  rl_transform *d_transforms = nullptr;
+  rl::DevMaterial *d_materials = nullptr;
+  rl::DevTexture *d_textures = nullptr;
+  rl::DevImage *d_images = nullptr;
+  float *d_image_pool = nullptr;
+  rl_perlin *d_perlins = nullptr;
+  // RTC
+  rl::DevTri *d_tris = nullptr;
+  rl_rtc_transformed *d_xforms = nullptr;
+  rl_rtc_material *d_rmaterials = nullptr;
+  rl_rtc_light *d_lights = nullptr;
+  rl_rtc_shape *d_shapes = nullptr;
+  rl_rtc_csg *d_csgs = nullptr;
+  rl_rtc_pattern *d_patterns = nullptr;
+  rl::RtcGuard *d_guards = nullptr;
+  // per-scene scratch: [0] work counter (u32), [64..] 8 x u64 stats, [128..] scheduler debug counters
+  unsigned char *d_scratch = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // status of the last asynchronous render (opt_stats == NULL): the 8 stats words copied to pinned host memory on the render's
+  // stream, and the event that follows the copy (rl_render_status waits for it)
+  unsigned long long *h_status = nullptr;
+  hipEvent_t ev_done = nullptr;
+  bool async_pending = false;
+  // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
+  uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_keys = nullptr, *d_tile_iota = nullptr;
+  void *d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  size_t lpt_pix = 0, lpt_tiles = 0;
+  // multi-GPU: this replica's row shard / on replica 0 the gather buffer [G][max_rows][W][3]
+  double *d_shard = nullptr;
+  size_t shard_bytes = 0;
+  uint32_t *d_pix_rays = nullptr;  // debug (tools/): per-pixel ray counts of the last counting render
+  void *exp = nullptr;             // experimental kernels' work buffers (rl_render.hip, RL_EXPERIMENTAL builds only)
+};
+
+namespace rl {
+
+int set_err_public(int code, const std::string &m);
+bool lib_ready();
+int n_contexts();
+DevCtx &context(int i);
+int use_context(int i);  // hipSetDevice(context(i).device)
+
+// Launch-only halves of the render entry points (rl_render.hip): enqueue everything on `stream`, never synchronise.  With
+// want_stats the caller finishes with collect_stats (which synchronises the stream).
+int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, void *d_out,
+                        hipStream_t stream, bool want_stats);
+int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out, hipStream_t stream,
+                      bool want_stats);
+int collect_stats(const rl_scene *scene, hipStream_t stream, rl_stats *st);  // RL_OK / RL_E_DEGENERATE / RL_E_DEVICE
+void add_stats(rl_stats *acc, const rl_stats &s);                             // sums counters, max of kernel_ms
+
+}  // namespace rl

@@ -168,3 +168,32 @@ def test_rtc_lighting_six_cases(rl, oracle):
     assert np.allclose(L((0, 10, -10), (0, -t, -t)), 1.6364, atol=1e-5)
     assert tuple(L((0, 0, 10), (0, 0, -1))) == (0.1, 0.1, 0.1)
     assert tuple(L((0, 0, -10), (0, 0, -1), 0.0)) == (0.1, 0.1, 0.1)
+
+
+def test_oracle_bvh_new_known_structure(oracle):
+    """Bvh::new (bvh.rs:22-60) + find_longest_axis (bvh.rs:63-77) on five unit boxes spread along x, by hand:
+    root box = union, longest axis x -> sorted by x.min -> [0 1 | 2 3 4]; left = leaf(0, 1); right: 3 boxes -> [2 | 3 4]."""
+    centres = np.array([[8.0, 0, 0], [0.0, 0, 0], [4.0, 0.5, 0], [2.0, 0, 0.25], [6.0, 0, 0]])
+    boxes = np.empty((5, 6))
+    boxes[:, 0::2], boxes[:, 1::2] = centres - 0.5, centres + 0.5
+    prims = np.zeros(5, dtype=[("kind", "<u4"), ("index", "<u4")])
+    prims["kind"], prims["index"] = 1, np.arange(5) + 10
+    nodes = oracle.bvh_build(boxes, prims, node_base=100)
+    # creation order: root, left(leaf 1,3), right, right.left(leaf 2), right.right(leaf 4,0)
+    assert len(nodes) == 5
+    root, left, right, rl_, rr = nodes
+    assert list(root["bbox"]) == [-0.5, 8.5, -0.5, 1.0, -0.5, 0.75]
+    assert [tuple(c) for c in root["child"]] == [(5, 101), (5, 102)]
+    assert left["n_children"] == 2 and [tuple(c) for c in left["child"]] == [(1, 11), (1, 13)]
+    assert list(left["bbox"]) == [-0.5, 2.5, -0.5, 0.5, -0.5, 0.75]
+    assert [tuple(c) for c in right["child"]] == [(5, 103), (5, 104)] and list(right["bbox"])[:2] == [3.5, 8.5]
+    assert rl_["n_children"] == 1 and tuple(rl_["child"][0]) == (1, 12)
+    assert rr["n_children"] == 2 and [tuple(c) for c in rr["child"]] == [(1, 14), (1, 10)]
+    # y longest only when strictly larger than x AND z (bvh.rs:64-76): equal sizes fall through to z
+    eq = np.array([[0.0, 1, 0, 1, 0, 1], [0.0, 1, 0, 1, 5, 6], [0.0, 1, 0, 1, 2, 3]])
+    eq = np.vstack([eq, [0.0, 6, 0, 6, 0, 1]])  # union: x 6, y 6, z 6 -> not x (6 > 6 false), not y -> z
+    p4 = np.zeros(4, dtype=prims.dtype)
+    p4["kind"], p4["index"] = 1, np.arange(4)
+    n4 = oracle.bvh_build(eq, p4)
+    assert [tuple(c) for c in n4[1]["child"]] == [(1, 0), (1, 3)]  # sorted by z.min, stable: boxes 0 and 3 (z.min 0) first
+    assert [tuple(c) for c in n4[2]["child"]] == [(1, 2), (1, 1)]

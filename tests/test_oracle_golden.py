@@ -64,9 +64,9 @@ def test_rtc_golden_csg_scene_byte_exact(rl, oracle, golden):
 def test_rtc_golden_mirror_scene(rl, oracle, golden):
     # tests/ray_tracer.rs:56-240: planes, glass sphere with an air pocket (reflection + refraction + Schlick, depth 5),
     # striped cube, Bounded(Transformed(Group)) of spheres.  59,999 of 60,000 pixels are byte-identical; pixel (23, 95)
-    # lies on a stripe boundary seen through the left mirror wall and flips when sin(-pi/3) of that wall's rotation_y
-    # changes by one ulp (checked: either neighbouring double reproduces the golden in all 60,000 pixels) — the golden
-    # was produced with another libm's sin/cos, so that pixel is outside what this container can pin.
+    # lies on a stripe boundary seen through the left mirror wall and flips with the last bit of sin / cos(-pi/3) of that wall's
+    # rotation_y (the next test: the other faithful roundings of the two values reproduce the golden in all 60,000 pixels) — the
+    # golden was produced with another libm's sin/cos, so that pixel is outside what this container can pin.
     expected = golden("test_mirror_scene.ppm.gz")
     assert hashlib.md5(expected).hexdigest() == "3f29ba2e266df2107fbcb2de23032043"
     world = rl.RtcWorld.test_mirror_scene(300, 200)
@@ -76,3 +76,52 @@ def test_rtc_golden_mirror_scene(rl, oracle, golden):
     ys, xs = np.nonzero((got != want).any(axis=2))
     assert len(ys) <= 1
     assert all((x, y) == (23, 95) for x, y in zip(xs, ys))
+
+
+def test_rtc_golden_mirror_scene_is_exact_with_faithfully_rounded_sin_cos(rl, oracle, golden):
+    """The one tolerated pixel of test_rtc_golden_mirror_scene is libm noise in a HOST INPUT of the ABI, not arithmetic of the hot
+    path.  The left mirror wall is rotation_y(-FRAC_PI_3) (tests/ray_tracer.rs:100-101).  glibc returns the correctly rounded
+    sin = -0.8660254037844387 (error 0.07 ulp) and cos = 0.4999999999999999 (0.16 ulp); with the OTHER faithful roundings a libm
+    may return — sin = -0.8660254037844386 (0.93 ulp) together with cos = 0.49999999999999994 (0.67 ulp) — the oracle reproduces
+    all 60,000 golden pixels byte for byte (so do two further one-ulp combinations; the correctly rounded pair does not, at
+    exactly pixel (23, 95)).  The golden was therefore rendered with another libm (the reference ships run.ps1: Windows)."""
+    import ctypes as C
+    import math
+    api = rl.api
+    expected = golden("test_mirror_scene.ppm.gz")
+    world = rl.RtcWorld.test_mirror_scene(300, 200)
+    desc = api.RtcSceneDesc.from_address(world.desc)
+    objects = np.ctypeslib.as_array(C.cast(desc.objects, C.POINTER(C.c_uint32)), shape=(desc.n_objects, 2))
+    assert objects[1][0] == api.O_TRANSFORMED  # World.objects[1] = left_wall (tests/ray_tracer.rs:216)
+    k = int(objects[1][1])
+    recs = np.frombuffer((C.c_char * (desc.n_transformeds * api.RTC_TRANSFORMED.itemsize)).from_address(desc.transformeds), dtype=api.RTC_TRANSFORMED)
+    L = api.host_lib()
+    FRAC_PI_2, FRAC_PI_3 = 1.57079632679489661923132169163975144, 1.04719755119659774615421446109316763  # std::f64::consts (pi / 3.0 is one ulp off)
+
+    def wall(s, c):  # sequence([rotation_x(pi/2), rotation_y' (sin = s, cos = c), translation(-8, 0, 0)]) = T * (Ry' * (Rx * I))  (transformation.rs:68-72)
+        rx, ry, acc, tmp = (np.zeros(16) for _ in range(4))
+        L.rlh_rtc_rotation(0, FRAC_PI_2, rx.ctypes.data)
+        ry[:] = [c, 0, s, 0, 0, 1, 0, 0, -s, 0, c, 0, 0, 0, 0, 1]
+        t = np.array([1.0, 0, 0, -8.0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1])
+        ident = np.eye(4).ravel().copy()
+        L.rlh_rtc_matmul(rx.ctypes.data, ident.ctypes.data, acc.ctypes.data)
+        L.rlh_rtc_matmul(ry.ctypes.data, acc.ctypes.data, tmp.ctypes.data)
+        L.rlh_rtc_matmul(t.ctypes.data, tmp.ctypes.data, acc.ctypes.data)
+        return api.rtc_transformed(acc, recs[k]["child"]["kind"], recs[k]["child"]["index"])
+
+    s0, c0 = math.sin(-FRAC_PI_3), math.cos(-FRAC_PI_3)
+    assert (s0, c0) == (-0.8660254037844387, 0.4999999999999999)
+    assert wall(s0, c0).tobytes() == recs[k].tobytes()  # the reconstruction is the record the scene holds
+    want = np.array(expected.split()[4:], dtype=int).reshape(200, 300, 3)
+
+    def mismatches(s, c):
+        recs[k] = wall(s, c)
+        img = oracle.rtc_render(world.desc, world.camera, aa=1)
+        got = np.array(rl.canvas_ppm(img).split()[4:], dtype=int).reshape(200, 300, 3)
+        ys, xs = np.nonzero((got != want).any(axis=2))
+        return sorted(zip(xs.tolist(), ys.tolist()))
+
+    assert mismatches(-0.8660254037844386, 0.49999999999999994) == []  # both faithfully rounded the other way
+    assert mismatches(-0.8660254037844386, 0.49999999999999983) == []
+    assert mismatches(-0.8660254037844388, c0) == []
+    assert mismatches(s0, c0) == [(23, 95)]
