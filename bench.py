@@ -15,11 +15,13 @@ the render) and gathered to rank 0 over RCCL/xGMI once per step — inside the t
 It never prints a line whose n_gpus differs from --gpus.
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline     — the kernel is VALU-issue-bound (the scene lives in LDS / L2; measured HBM traffic is the framebuffer), so the
-                 bound is the chip's vector-instruction issue capacity: achieved = VALU lane-operations per ray (rocprofv3 SQ
-                 counters of the same kernel on the same workload, profiles/valu.json: instruction counts are a property of the
-                 workload) x rays of THIS run / kernel time of THIS run (HIP events on the launch stream), binary64 instructions
-                 weighted 2x (they hold the pipe twice as long); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
+  roofline     — the kernel is bound by VALU issue under divergence (the scene lives in LDS / L2; measured HBM traffic is the
+                 framebuffer), so the bound is the chip's vector-instruction issue capacity: achieved = VALU lane-operations per
+                 ray (rocprofv3 SQ counters of the same kernel on the same workload, profiles/valu.json: instruction counts are a
+                 property of the workload) x rays of THIS run / kernel time of THIS run (HIP events on the launch stream),
+                 binary64 instructions weighted 2x (they hold the pipe twice as long); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
+                 frac = valu_issue_frac (share of the SIMDs' issue slots used) x lanes_active_frac (lanes doing work per
+                 instruction).  lds_frac = LDS-array busy cycles / CU cycles.
                  `traffic` = measured HBM bytes per launch (profiles/), algorithmic_bytes = SURVEY.md §8d's figure, both reported,
                  neither the bound.
   check        — after the timed loop: the timed frame equals the counting kernel's frame bit for bit; 8 full-spp rows of the real
@@ -41,7 +43,6 @@ sys.path.insert(0, ROOT)
 
 CLOCK_GHZ, N_CU, N_SIMD, SIMD_LANES = 2.4, 256, 4, 32  # /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters, SIMD-32)
 VALU_PEAK_TLANEOPS = N_CU * N_SIMD * SIMD_LANES * CLOCK_GHZ / 1e3  # 78.6 T lane-ops/s (one binary32 op per lane per clock)
-LDS_PEAK_GBS = N_CU * 128 * CLOCK_GHZ                             # 128 B/clk/CU
 
 
 def parse_args():
@@ -231,12 +232,14 @@ def main():
             wave_insts = vp["valu_issue_slots_per_ray"]            # wave-instructions, binary64 counted twice (2-cycle slots)
             achieved = lane_ops * rank_rays / k_s / 1e12
             issue = wave_insts * rank_rays / k_s / (N_CU * N_SIMD * CLOCK_GHZ * 1e9 / 2.0)
-            lds_gbs = vp["lds_bytes_per_ray"] * rank_rays / k_s / 1e9
+            lds_frac = vp["lds_array_cycles_per_ray"] * rank_rays / k_s / (N_CU * CLOCK_GHZ * 1e9)  # LDS-array busy cycles / CU cycles
             roof.update({"achieved": achieved, "frac": achieved / VALU_PEAK_TLANEOPS,
                          "valu_issue_frac": issue, "lanes_active_frac": vp["lanes_active_frac"],
-                         "lds_gbs": lds_gbs, "lds_frac": lds_gbs / LDS_PEAK_GBS, "lds_bank_conflict_frac": vp["lds_bank_conflict_frac"],
+                         "lds_frac": lds_frac, "lds_bank_conflict_frac": vp["lds_bank_conflict_frac"],
+                         "valu_wave_insts_per_ray": vp["valu_wave_insts_per_ray"], "valu_issue_slots_per_ray": wave_insts,
                          "fp64_flop_per_ray": vp.get("fp64_flop_per_ray"),
                          "fp64_tflops": (vp["fp64_flop_per_ray"] * rank_rays / k_s / 1e12) if vp.get("fp64_flop_per_ray") else None,
+                         "fp64_peak_tflops_unfused": 39.3,
                          "traffic": vp.get("hbm_bytes_per_launch"),
                          "per_ray_figures_from": vp.get("source"),
                          "note": "per-ray instruction counts are rocprofv3 SQ counters of this kernel on this workload (profiles/, not collected in this run); "

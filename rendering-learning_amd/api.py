@@ -112,9 +112,24 @@ _host = None
 _render = None
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7; librl_render.so links the system one (/opt/rocm).  A process that
+    ends up with BOTH sees the GPU only through whichever initialises first.  If torch is importable it is therefore imported
+    BEFORE the product library is loaded: the dynamic loader then resolves librl_render.so's libamdhip64.so.7 to the copy torch
+    already mapped (same SONAME) and the process has one runtime.  RL_NO_TORCH_PRELOAD=1 skips this (pure C / ctypes hosts)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("RL_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def host_lib():
     global _host
     if _host is None:
+        _one_hip_runtime()  # librl_host.so links librl_render.so
         if not os.path.exists(HOST_LIB):
             raise RuntimeError(f"{HOST_LIB} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(HOST_LIB)
@@ -159,6 +174,7 @@ def render_lib():
     """The HIP product library. Fails loudly when it is not built."""
     global _render
     if _render is None:
+        _one_hip_runtime()
         if not os.path.exists(RENDER_LIB):
             raise RuntimeError(f"{RENDER_LIB} not built — the HIP extension is required (no CPU fallback); "
                                "run `python -c 'import __graft_entry__ as g; g.build()'`")
@@ -224,7 +240,14 @@ def render_status(world, allow_degenerate=False):
     st = Stats()
     rc = render_lib().rl_render_status(world.device(), C.byref(st))
     _check(rc, allow_degenerate)
-    return {"rays": st.rays, "flagged": st.flagged, "rc": rc}
+    L = render_lib()
+    L.rl_debug_slow_traces.restype = C.c_uint64
+    return {"rays": st.rays, "flagged": st.flagged, "rc": rc, "slow_traces": L.rl_debug_slow_traces()}
+
+
+def set_fast_traversal(on):
+    """Tests / tools: counter-free renders of small sphere scenes use the fast (ordered, reject-only) traversal unless switched off."""
+    render_lib().rl_debug_set_fast_traversal(int(bool(on)))
 
 
 def has_experimental():

@@ -46,6 +46,19 @@ struct alignas(16) CompactOp {  // 32 B: the wave kernel's LDS form of a box / g
 };
 static_assert(sizeof(CompactOp) == 32, "CompactOp must be 32 B");
 
+// Node of the wave kernel's FAST traversal structure (rl_fast_bvh.cpp): a binary tree over the spheres built by the surface-area
+// heuristic, one 64-byte record per inner node holding BOTH children's boxes (binary32, rounded outwards) so that one step tests
+// the two of them and descends into the nearer one first.  The boxes only ever REJECT (rl_rtiow_wave.h).  child = eA | eB << 16 with
+// entry ids e: inner node i -> i, sphere s -> n_inner + s; FAST_NONE = empty stack.
+static const uint32_t FAST_NONE = 1023u;
+static const uint32_t FAST_MAX_DEPTH = 14;  // the per-lane stack holds 15 ten-bit entries above its sentinel
+struct alignas(16) FastNode {
+  float box[2][6];  // [child][x.min, x.max, y.min, y.max, z.min, z.max]
+  uint32_t child;   // eA | eB << 16
+  uint32_t pad[3];
+};
+static_assert(sizeof(FastNode) == 64, "FastNode must be 64 B");
+
 struct alignas(16) DevSphere {  // 64 B
   double c0[3];
   double dc[3];   // center1 - center0 (sphere.rs:27: p2 - p1), 0 when stationary
@@ -95,6 +108,21 @@ struct RtiowProgram {
   bool has_planars = false, has_instances = false, has_images = false, has_noise = false, has_sphere_uv = false;
   uint32_t max_instance_depth = 0;
 };
+
+// Where the reject-only boxes' padding is valid (rl_fast_bvh.cpp).
+struct GuardFrame {
+  double center[3];  // centre of the scene's bounding box
+  double half;       // half of its diagonal
+  double reach;      // the camera must be within this distance of `center` (checked per render)
+  double L;          // bound on |ray origin - sphere centre| for every ray the kernel traces
+  double M;          // bound on every coordinate magnitude of origins and centres
+  bool normals_safe; // no Sphere::hit of this scene can trip the from_normalized assert (vec3.rs:219) for rays inside the frame
+};
+GuardFrame guard_frame(const rl_rtiow_scene_desc &d);
+double guard_pad(const GuardFrame &f, double radius);  // how far outside a sphere a reject-only box must stay
+// Fast traversal structure for a sphere-only scene; false when the scene does not qualify (too many spheres for the LDS budget,
+// degenerate spheres, spheres referenced more than once or not at all...).  root_entry: entry id a new ray starts at.
+bool build_fast_bvh(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, const GuardFrame &f, std::vector<FastNode> &nodes, uint32_t &root_entry);
 
 // Returns RL_OK or RL_E_INVALID (err filled).
 int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &out, std::string &err);

@@ -39,6 +39,8 @@ int g_cus = 0;
 size_t g_lds_max = 65536;
 int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
 bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
+unsigned long long g_last_slow_traces = 0;
+bool g_fast_traversal = true;  // counter-free renders of LDS-sized sphere scenes use the fast traversal (RL_FAST=0 disables; A/B only)
 
 int set_err(int code, const std::string &m) {
   g_err = m;
@@ -157,9 +159,10 @@ int rl_init(int device) {
   if (rc != RL_OK) return rc;
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
+  if (const char *v = std::getenv("RL_FAST")) g_fast_traversal = std::string(v) != "0";
   g_ready = true;
   return RL_OK;
 }
@@ -189,7 +192,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -233,44 +236,6 @@ static int scene_common(rl_scene *s) {
 // A ray that certainly misses a sphere's box certainly misses the sphere, so the expensive binary64 Sphere::hit is skipped
 // for it (65 % of the leaf visits of BASELINE configs[1] end without a new closest hit).  Needs every sphere to be
 // referenced exactly once (*guards_ok = false otherwise).
-// Where the guard boxes' padding is valid.  A guard may only reject a ray that Sphere::hit (sphere.rs:32-75) would ALSO report as a
-// miss, and Sphere::hit decides on the sign of the ROUNDED discriminant half_b^2 - a*c.  For a ray whose line passes the centre at
-// distance b the exact value is a*(r^2 - b^2); the rounded one differs by at most ~16u*a*|oc|^2 (products and sums of the three
-// dot products) + 4u*a*M*|oc| (the rounding of oc = o - centre itself; M = largest coordinate involved), u = 2^-53.  A ray that
-// misses the box [c - r - pad, c + r + pad] has b >= r + pad, i.e. r^2 - b^2 <= -2*r*pad, so
-//     pad >= (8u*L^2 + 2u*M*L) / r      (L >= |oc|)
-// makes the rounded discriminant negative as well.  L and M follow from a FRAME: every ray origin the kernel ever uses is the
-// camera (checked against `reach` at render time, rtiow_render_launch) or a hit point on one of the scene's spheres.
-struct GuardFrame {
-  double center[3];  // centre of the scene's bounding box
-  double half;       // half of its diagonal
-  double reach;      // ray origins are within this distance of `center`
-  double M;          // bound on every coordinate magnitude of origins and centres
-};
-static GuardFrame guard_frame(const rl_rtiow_scene_desc &d) {
-  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (uint32_t i = 0; i < d.n_spheres; i++) {
-    const rl_sphere &sp = d.spheres[i];
-    double r = std::fabs(sp.radius);
-    for (int ax = 0; ax < 3; ax++) {
-      double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
-      lo[ax] = std::fmin(lo[ax], std::fmin(c0, c1) - r), hi[ax] = std::fmax(hi[ax], std::fmax(c0, c1) + r);
-    }
-  }
-  GuardFrame f{};
-  double diag2 = 0.0, cmax = 0.0;
-  for (int ax = 0; ax < 3; ax++) {
-    if (!(lo[ax] <= hi[ax])) lo[ax] = hi[ax] = 0.0;  // no spheres (or NaN): an empty frame
-    f.center[ax] = 0.5 * (lo[ax] + hi[ax]);
-    diag2 += (hi[ax] - lo[ax]) * (hi[ax] - lo[ax]);
-    cmax = std::fmax(cmax, std::fmax(std::fabs(lo[ax]), std::fabs(hi[ax])));
-  }
-  f.half = 0.5 * std::sqrt(diag2);
-  f.reach = 4.0 * f.half + 1.0;  // a camera up to four scene radii away keeps the guards; farther away the render uses the unguarded ops
-  f.M = cmax + f.reach;
-  return f;
-}
-
 static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out, const rl_rtiow_scene_desc *guards = nullptr, bool *guards_ok = nullptr,
                          const GuardFrame *frame = nullptr) {
   const uint32_t n0 = (uint32_t)ops.size();
@@ -329,9 +294,8 @@ static uint32_t link_ops(const std::vector<DevOp> &ops, std::vector<DevOp> &out,
         for (int ax = 0; ax < 3; ax++) {
           double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
           double lo = std::fmin(c0, c1) - r, hi = std::fmax(c0, c1) + r;
-          // this box only ever rejects: keep it outside the sphere by more than Sphere::hit's rounding can bridge (GuardFrame)
-          const double u = 1.1102230246251565e-16, L = frame ? frame->reach + frame->half : 0.0, M = frame ? frame->M : 0.0;
-          double pad = std::fmax(1e-9 * (std::fabs(lo) + std::fabs(hi) + r), 8.0 * (8.0 * u * L * L + 2.0 * u * M * L) / r);  // 8x the bound; r = 0: inf -> NaN box
+          // this box only ever rejects: keep it outside the sphere by more than Sphere::hit's rounding can bridge (rl_fast_bvh.cpp guard_pad)
+          double pad = std::fmax(1e-9 * (std::fabs(lo) + std::fabs(hi) + r), frame ? guard_pad(*frame, r) : 0.0);  // r = 0: inf -> NaN box
           G.box[2 * ax] = lo - pad, G.box[2 * ax + 1] = hi + pad;
         }
         for (int ax = 0; ax < 6; ax++)
@@ -401,6 +365,8 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
       std::memcpy(H->guard_center, frame.center, sizeof frame.center);
       H->guard_reach = frame.reach;
     }
+    // the fast traversal structure of the timed (counter-free) kernel: ordered binary tree, reject-only boxes (rl_fast_bvh.cpp)
+    if (!H->cops.empty() && !build_fast_bvh(*desc, rt, frame, H->fast_nodes, H->fast_root)) H->fast_nodes.clear(), H->fast_root = FAST_NONE;
   }
   out = H;
   return RL_OK;
@@ -417,7 +383,8 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (rc = upload(rt.materials, &s->d_materials)) || (rc = upload(rt.textures, &s->d_textures)) || (rc = upload(rt.images, &s->d_images)) ||
       (rc = upload(rt.image_pool, &s->d_image_pool)) || (rc = upload(rt.perlins, &s->d_perlins)) || (rc = scene_common(s)) ||
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
-      (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits))))) {
+      (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
+      (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes)))) {
     destroy_one(s);
     return nullptr;
   }
@@ -591,6 +558,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.lops = scene->d_lops, P.entry0 = H.entry0, P.sphere_flat = scene->d_sphere_flat;
   const uint32_t n_cops = (uint32_t)H.cops.size();
   P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
+  P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;
@@ -654,6 +622,12 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     for (int k = 0; k < 3; k++) disk += std::fabs(cam->defocus_disk_u[k]) + std::fabs(cam->defocus_disk_v[k]);
     if (!(std::sqrt(far) + disk <= H.guard_reach)) fits_compact = false;  // also for NaN
   }
+  // 1029 = the FAST traversal (ordered binary tree, reject-only boxes, exact re-trace of ambiguous rays): counter-free renders only —
+  // its box / sphere test counts are not the reference's, so a render that asks for rl_stats runs the counting kernel (1027)
+  const size_t fast_bytes = ((size_t)P.n_fast_inner * sizeof(FastNode) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const bool fits_fast = fits_compact && H.fast_root != FAST_NONE && !want_stats && (size_t)16 * 1024 * sizeof(unsigned long long) + fast_bytes <= g_lds_max &&
+                         g_fast_traversal;
+  if (variant == 1029 && (general || !fits_fast)) variant = 0;
   if (variant == 1027 && (general || !fits_compact)) variant = 0;
   if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
@@ -663,7 +637,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     // else 3 (or 2) waves per SIMD with the whole scene in LDS; else 4 waves per SIMD reading everything from HBM / L2
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
-    variant = fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
+    variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
   auto launch_variant = [&]() -> int {
     int rc;
@@ -712,6 +686,10 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp);
       rc = want_stats ? launch(rtiow_wave_kernel<NT, 2, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 2, false>, NT, rb, false);
+    } else if (variant == 1029) {  // 4 waves per SIMD: rings + fast traversal nodes in LDS, spheres read from L2; never a counting render
+      constexpr int NT = 1024;
+      size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;
+      rc = launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
     } else if (variant == 1027) {  // 4 waves per SIMD: rings + compact guarded ops in LDS, spheres read from L2
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + compact_bytes;
@@ -800,6 +778,7 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
   if (!scene) return set_err(RL_E_INVALID, "bad argument");
   rl_stats acc;
   std::memset(&acc, 0, sizeof acc);
+  g_last_slow_traces = 0;
   size_t n = scene->replicas.empty() ? 1 : scene->replicas.size();
   for (size_t g = 0; g < n; g++) {
     rl_scene *r = const_cast<rl_scene *>(scene->replicas.empty() ? scene : scene->replicas[g]);
@@ -809,6 +788,7 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
     HIP_TRY(hipEventSynchronize(r->ev_done));
     r->async_pending = false;
     acc.rays += r->h_status[0], acc.flagged += r->h_status[6];
+    g_last_slow_traces += r->h_status[7];
   }
   if (n > 1) rl::use_context(0);
   if (st) *st = acc;
@@ -819,6 +799,9 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
 // Not part of the ABI (tests / tools only): force an RTIOW kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave).
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
+void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
+// rays of the render rl_render_status last waited for that the fast traversal re-traced in the reference's order
+unsigned long long rl_debug_slow_traces(void) { return g_last_slow_traces; }
 int rl_debug_has_experimental(void) {
 #ifdef RL_EXPERIMENTAL
   return 1;

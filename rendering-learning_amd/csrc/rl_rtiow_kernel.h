@@ -31,6 +31,8 @@ struct RtiowParams {
   const CompactOp *cops;    // wave kernel LDS_SCENE = 3: guarded compact ops (n_ops originals + one guard per sphere)
   const uint32_t *movbits;  // ... one bit per sphere: Center::Moving
   uint32_t n_cops, centry0;
+  const FastNode *fast_nodes;  // wave kernel LDS_SCENE = 4: the fast traversal structure (n_fast_inner nodes; entry ids, rl_program.h)
+  uint32_t n_fast_inner, fast_root;
   rl_rtiow_camera cam;
   uint32_t key[8];
   uint64_t first_sample;

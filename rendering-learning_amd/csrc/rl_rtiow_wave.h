@@ -163,8 +163,89 @@ __device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, 
 }
 
 // LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2,
-// 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2
+// 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2,
+// 4 = FAST traversal (counter-free renders only): P.fast_nodes in LDS — see below
 typedef __attribute__((address_space(3))) CompactOp LdsCompactOp;
+typedef float Float4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const Float4 LdsFloat4;
+typedef __attribute__((address_space(3))) const uint32_t LdsU32;
+
+// ---- FAST traversal (LDS_SCENE = 4).  The reference's fold over its BVH visits ~40 boxes and ~4.7 spheres per ray because its tree
+// is a median split walked in stored order.  For the RESULT of the fold only the smallest accepted root matters (rl_fast_bvh.cpp), so
+// the timed kernel walks its own surface-area-heuristic binary tree instead: one TRAV step fetches a 64-byte node with BOTH children's
+// boxes, tests the two with the binary32 filter in reject-only form (a box is skipped only when it is CERTAINLY missed inside
+// [1e-10, closest]), descends into the nearer child and pushes the farther one on a 16-entry stack held in five VGPRs (ten-bit entry
+// ids, v_alignbit shifts) — ~12 steps and ~1.9 Sphere::hit per ray.  Whenever the visiting ORDER could influence the reference's answer
+// the ray is flagged and re-traced by fast_slow_trace, the reference's own fold with exact divisions:
+//   * two roots within 1e-7 relative of each other (exact ties go to the LAST sphere in the reference's order; `tmin < closest`
+//     pruning on the reference's boxes),
+//   * a grazing hit (chord below 1e-6 relative: the reference's unpadded leaf box may or may not be passed),
+//   * a hit whose outward normal trips the from_normalized assert (vec3.rs:219: the panic-site count is order dependent),
+//   * a ray outside the filter's range (zero / denormal-scale / huge direction component, far-away origin).
+static const uint32_t FAST_SLOW = 0xFFFFFFFFu;  // pc of a lane in ST_LEAF that must re-trace its ray in the reference's order
+
+// Sphere::hit (sphere.rs:32-75) with the acceptance window widened by the tie band; same arithmetic, same root values.
+__device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time, double &closest, uint32_t &hit_prim, bool &amb) {
+  D3 c0 = ld3(s.c0);
+  D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+  D3 oc = o - center;
+  double a = len2(d);
+  double half_b = dot(oc, d);
+  double c = len2(oc) - s.r2;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return;
+  double sq = sqrt(disc);
+  double r_l = (-half_b - sq) / a;
+  double r_u = (-half_b + sq) / a;
+  const double band = 1e-7 * (fabs(r_l) + fabs(r_u));
+  const double hi = closest + band;  // +inf stays +inf
+  double t;
+  if (1e-10 <= r_l && r_l <= hi) t = r_l;
+  else if (1e-10 <= r_u && r_u <= hi) t = r_u;
+  else return;
+  D3 p = o + d * t;
+  D3 outward = (p - center) * s.inv_r;
+  double l2 = len2(outward);
+  bool bad_normal = !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
+  bool near_tie = hit_prim != NONE && fabs(t - closest) <= band;
+  bool grazing = sq <= 1e-6 * fabs(half_b);
+  amb = amb || bad_normal || near_tie || grazing;
+  if (t <= closest) closest = t, hit_prim = payload;
+}
+
+// The reference's fold, verbatim: threaded program in stored order, exact divisions, Sphere::hit with ray_t.max = closest so far
+// (bvh.rs:79-95, hittable/mod.rs:88-111).  Returns the number of from_normalized asserts tripped on the way.
+__device__ __forceinline__ uint32_t fast_slow_trace(const DevOp *ops, const DevSphere *spheres, D3 o, D3 d, double time, double &closest, uint32_t &hit_prim) {
+  Hit h{__longlong_as_double(0x7FF0000000000000ll), NONE};
+  uint32_t flags = 0, pc = 0;
+#pragma unroll 1
+  for (;;) {
+    const DevOp &op = ops[pc];
+    uint32_t code = op.code & 0xFFu;
+    if (code == OP_END) break;
+    uint32_t a = op.a, b = NONE, next = pc + 1;
+    if (code != OP_SPHERE) {  // OP_BOX / OP_BOX_SPH
+      double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+      if (!aabb_hit(bx, o, d, 1e-10, h.t)) {
+        pc = op.skip;
+        continue;
+      }
+      if (code == OP_BOX) {
+        pc = next;
+        continue;
+      }
+      b = op.b, next = op.skip;
+    }
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+      uint32_t payload = k == 0 ? a : b;
+      if (payload != NONE && sphere_hit(spheres[payload & SPH_INDEX], payload, o, d, time, 1e-10, h)) flags++;
+    }
+    pc = next;
+  }
+  closest = h.t, hit_prim = h.prim;
+  return flags;
+}
 
 template <int NT, int LDS_SCENE, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
@@ -172,15 +253,25 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   const int tid = threadIdx.x;
   // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
   const size_t bits_words = ((size_t)P.n_spheres + 31) / 32 + 1;
-  const size_t scene_lds = LDS_SCENE == 3 ? (((size_t)P.n_cops * sizeof(CompactOp) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
-                           : LDS_SCENE  ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0))
-                                        : 0;
+  const size_t scene_lds = LDS_SCENE == 4   ? (((size_t)P.n_fast_inner * sizeof(FastNode) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
+                           : LDS_SCENE == 3 ? (((size_t)P.n_cops * sizeof(CompactOp) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
+                           : LDS_SCENE      ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0))
+                                            : 0;
   unsigned long long *s_rng = (unsigned long long *)(smem + scene_lds);  // [16][NT]
   const unsigned char *opbase = (const unsigned char *)P.lops;  // pc is an index (HBM) or a byte offset (LDS) into this
   const DevSphere *spheres = P.spheres;
   const uint32_t *s_bits = nullptr;  // LDS_SCENE == 3: one bit per sphere (Center::Moving)
   const uint32_t lds_base = (uint32_t)(uintptr_t)smem;  // the dynamic LDS segment's own address (low half of the flat address)
-  if (LDS_SCENE == 3) {
+  if (LDS_SCENE == 4) {
+    const uint4 *g = (const uint4 *)P.fast_nodes;
+    uint4 *l = (uint4 *)smem;
+    for (uint32_t i = tid; i < P.n_fast_inner * 4u; i += NT) l[i] = g[i];
+    uint32_t *bl = (uint32_t *)(smem + (size_t)P.n_fast_inner * sizeof(FastNode));
+    for (uint32_t i = tid; i < (uint32_t)bits_words; i += NT) bl[i] = P.movbits[i];
+    __syncthreads();
+    opbase = smem;
+    s_bits = bl;
+  } else if (LDS_SCENE == 3) {
     const uint4 *g = (const uint4 *)P.cops;
     uint4 *l = (uint4 *)smem;
     for (uint32_t i = tid; i < P.n_cops * 2u; i += NT) {
@@ -225,7 +316,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     __syncthreads();
     opbase = smem;
   }
-  const uint32_t entry0 = LDS_SCENE == 3 ? ((P.centry0 & 0xE0000000u) | (((P.centry0 & 0x1FFFFFFFu) << 5) + lds_base))
+  const uint32_t entry0 = LDS_SCENE == 4   ? 0u  // fast traversal: rays start through fast_start()
+                          : LDS_SCENE == 3 ? ((P.centry0 & 0xE0000000u) | (((P.centry0 & 0x1FFFFFFFu) << 5) + lds_base))
                           : LDS_SCENE  ? ((P.entry0 & 0xE0000000u) | ((P.entry0 & 0x1FFFFFFFu) << 6))
                                        : P.entry0;
   const rl_rtiow_camera &cam = P.cam;
@@ -246,8 +338,45 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   RayAux32 ra32 = ray_aux32(ra);
   double time = 0.0, closest = INF;
   uint32_t pc = 0, hit_prim = NONE, depth = 0;
-  uint32_t c_rays = 0, c_flag = 0;
+  uint32_t c_rays = 0, c_flag = 0, c_slow = 0;  // c_slow: rays the fast traversal handed to the reference-order fold
   unsigned long long c_nodes = 0, c_sph = 0, c_words = 0;
+
+  // fast traversal (LDS_SCENE = 4): 16 ten-bit entry ids in five registers, newest in the low bits of stk0; all ones = empty
+  uint32_t stk0 = ~0u, stk1 = ~0u, stk2 = ~0u, stk3 = ~0u, stk4 = ~0u;
+  bool amb = false;  // this ray must be re-traced in the reference's order
+  auto fast_push = [&](uint32_t e) {
+    stk4 = __builtin_amdgcn_alignbit(stk4, stk3, 22), stk3 = __builtin_amdgcn_alignbit(stk3, stk2, 22);
+    stk2 = __builtin_amdgcn_alignbit(stk2, stk1, 22), stk1 = __builtin_amdgcn_alignbit(stk1, stk0, 22);
+    stk0 = (stk0 << 10) | e;
+  };
+  auto fast_pop = [&]() -> uint32_t {
+    uint32_t e = stk0 & 1023u;
+    stk0 = __builtin_amdgcn_alignbit(stk1, stk0, 10), stk1 = __builtin_amdgcn_alignbit(stk2, stk1, 10);
+    stk2 = __builtin_amdgcn_alignbit(stk3, stk2, 10), stk3 = __builtin_amdgcn_alignbit(stk4, stk3, 10);
+    stk4 = (stk4 >> 10) | (FAST_NONE << 22);
+    return e;
+  };
+  auto fast_go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), a sphere (LEAF), or nothing left
+    if (e == FAST_NONE) {
+      if (amb) pc = FAST_SLOW, state = ST_LEAF;
+      else state = ST_SHADE;
+    } else if (e >= P.n_fast_inner) pc = e, state = ST_LEAF;
+    else pc = lds_base + (e << 6), state = ST_TRAV;
+  };
+  auto start_ray = [&]() {  // o, d set: per-ray constants of the box filter, then the first traversal state
+    ra = ray_aux(o, d);
+    if (!ra.fast_ok) ra.slack = INF;
+    ra32 = ray_aux32(ra);
+    closest = INF, hit_prim = NONE;
+    if (LDS_SCENE == 4) {
+      stk0 = stk1 = stk2 = stk3 = stk4 = ~0u;
+      amb = !(ra32.slack < __int_as_float(0x7F800000));  // outside the binary32 filter's range: the reference's order from the start
+      fast_go(amb ? FAST_NONE : P.fast_root);
+    } else {
+      pc = entry0 & 0x1FFFFFFFu;
+      state = entry0 >> 29;
+    }
+  };
 
   unsigned long long sc_exec[6] = {0, 0, 0, 0, 0, 0}, sc_pop[6] = {0, 0, 0, 0, 0, 0}, sc_cyc[6] = {0, 0, 0, 0, 0, 0};
   for (;;) {
@@ -289,7 +418,31 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           // the successor words already carry the state the lane enters there (rl_render.hip link_ops)
           uint32_t w_hit, w_miss;
           bool certain, hitb;
-          if (LDS_SCENE == 3) {  // 32-byte op: binary32 box + the two successor words
+          if (LDS_SCENE == 4) {  // one node = both children: reject-only binary32 tests, nearer child first, the other one pushed
+            LdsFloat4 *nd = (LdsFloat4 *)(size_t)pc;
+            const Float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+            const uint32_t w = *(LdsU32 *)(size_t)(pc + 48u);
+            const float c32 = (float)closest;
+            auto missed = [&](float b0, float b1, float b2, float b3, float b4, float b5, float &tmin) {
+              float t0x = fmaf(b0, ra32.invx, -ra32.oix), t1x = fmaf(b1, ra32.invx, -ra32.oix);
+              float t0y = fmaf(b2, ra32.invy, -ra32.oiy), t1y = fmaf(b3, ra32.invy, -ra32.oiy);
+              float t0z = fmaf(b4, ra32.invz, -ra32.oiz), t1z = fmaf(b5, ra32.invz, -ra32.oiz);
+              tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
+              float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), c32);
+              float diff = tmax - tmin;
+              float thresh = fmaf(tmin + fabsf(tmax), 4.76837158203125e-07f, ra32.slack);  // 8u(|tmin|+|tmax|) + slack (aabb_fast32)
+              return diff < -thresh;  // certainly tmin > tmax; false for NaN arithmetic: visit
+            };
+            float tA, tB;
+            const bool hitA = !missed(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tA);
+            const bool hitB = !missed(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tB);
+            const uint32_t eA = w & 0xFFFFu, eB = w >> 16;
+            const bool a_first = hitA && (!hitB || tA <= tB);
+            uint32_t first = a_first ? eA : eB;
+            if (hitA && hitB) fast_push(a_first ? eB : eA);
+            if (!(hitA || hitB)) first = fast_pop();
+            fast_go(first);
+          } else if (LDS_SCENE == 3) {  // 32-byte op: binary32 box + the two successor words
             const LdsCompactOp &op = *(const LdsCompactOp *)(size_t)pc;
             float bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
             w_hit = op.w_hit, w_miss = op.w_miss;
@@ -312,9 +465,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             if (!certain) hitb = aabb_hit(P.ops[LDS_SCENE ? (pc >> 6) : pc].box, o, d, 1e-10, closest);  // rare: exact divisions
             if (STATS) c_nodes++;
           }
-          uint32_t w = hitb ? w_hit : w_miss;
-          pc = w & 0x1FFFFFFFu;
-          state = w >> 29;
+          if (LDS_SCENE != 4) {
+            uint32_t w = hitb ? w_hit : w_miss;
+            pc = w & 0x1FFFFFFFu;
+            state = w >> 29;
+          }
         }
       };
       for (int it = 0; it < (int)P.tune[0]; it += 2) {  // two steps per population check
@@ -323,7 +478,20 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
         if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
       }
     } else if (pick == ST_LEAF) {
-      if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
+      if (LDS_SCENE == 4) {
+        if (state == ST_LEAF) {
+          if (pc == FAST_SLOW) {  // rare: the answer may depend on the visiting order -> the reference's own fold
+            c_flag += fast_slow_trace(P.ops, spheres, o, d, time, closest, hit_prim);
+            c_slow++;
+            state = ST_SHADE;
+          } else {
+            const uint32_t sidx = pc - P.n_fast_inner;
+            const uint32_t payload = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u);
+            fast_sphere_hit(spheres[sidx], payload, o, d, time, closest, hit_prim, amb);
+            fast_go(fast_pop());
+          }
+        }
+      } else if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
         uint32_t a, b, w;
         if (LDS_SCENE == 3) {  // a guard op: the ONE sphere it stands for (index = op index - n_ops), counted at the guard step
           const LdsCompactOp &op = *(const LdsCompactOp *)(size_t)pc;
@@ -418,11 +586,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           } else {
             c_rays++;
             pix_rays++;
-            ra = ray_aux(o, d);
-            if (!ra.fast_ok) ra.slack = INF;
-            ra32 = ray_aux32(ra);
-            pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
-            state = entry0 >> 29;
+            start_ray();
           }
         }
       }
@@ -510,11 +674,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           pix_rays++;
           o = p;
           d = nd;
-          ra = ray_aux(o, d);
-          if (!ra.fast_ok) ra.slack = INF;
-          ra32 = ray_aux32(ra);
-          pc = entry0 & 0x1FFFFFFFu, closest = INF, hit_prim = NONE;
-          state = entry0 >> 29;
+          start_ray();
         }
       }
     }
@@ -540,6 +700,10 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   if ((tid & 63) == 0 && v) atomicAdd(&P.stats[0], v);
   v = wave_sum((unsigned long long)c_flag);
   if ((tid & 63) == 0 && v) atomicAdd(&P.stats[6], v);
+  if (LDS_SCENE == 4) {
+    v = wave_sum((unsigned long long)c_slow);
+    if ((tid & 63) == 0 && v) atomicAdd(&P.stats[7], v);
+  }
   if (STATS) {
     v = wave_sum(c_nodes);
     if ((tid & 63) == 0) atomicAdd(&P.stats[1], v);

@@ -26,6 +26,8 @@ struct HostRtiow {
   std::vector<CompactOp> cops;  // guarded compact ops
   std::vector<uint32_t> movbits;
   uint32_t entry0 = 0, centry0 = 0;
+  std::vector<FastNode> fast_nodes;  // fast traversal structure (rl_fast_bvh.cpp); fast_root == FAST_NONE: the scene does not qualify
+  uint32_t fast_root = FAST_NONE;
   // the guard boxes' padding is rigorous for ray origins within guard_reach of guard_center (rl_render.hip link_ops)
   double guard_center[3] = {0, 0, 0}, guard_reach = 0;
 };
@@ -50,6 +52,7 @@ struct rl_scene {
   rl::DevMaterial *d_sphere_flat = nullptr;
   rl::CompactOp *d_cops = nullptr;
   uint32_t *d_movbits = nullptr;
+  rl::FastNode *d_fast_nodes = nullptr;
   rl::DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
   rl::DevPlanar *d_planars = nullptr;

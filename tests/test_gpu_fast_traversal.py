@@ -1,0 +1,186 @@
+"""GPU tier: the FAST traversal of the timed sphere kernel (rtiow_wave_kernel<1024, 4, false>: ordered binary tree with reject-only
+boxes, rays whose answer could depend on the visiting order re-traced by the reference's own fold — csrc/rl_fast_bvh.cpp,
+rl_rtiow_wave.h).  Its frames must equal the reference-order kernels' frames BIT FOR BIT and the oracle within the tight bar, in
+particular where order matters: coincident spheres (exact ties), grazing hits, axis-parallel rays, far-away origins, degenerate
+spheres.  `slow_traces` (rays handed to the reference-order fold) shows that the ambiguity detection fires where it must and
+almost never elsewhere."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _frames(rl, cam, world, allow_degenerate=False):
+    """(fast timed frame, reference-order timed frame, counting frame, status of the fast render)."""
+    import torch
+    api = rl.api
+    dev = torch.device("cuda", 0)
+
+    def timed():
+        buf = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device=dev)
+        cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+        st = api.render_status(world, allow_degenerate=allow_degenerate)
+        return buf.cpu().numpy(), st
+    fast, st = timed()
+    try:
+        api.set_fast_traversal(False)
+        ref_order, st0 = timed()
+    finally:
+        api.set_fast_traversal(True)
+    assert st0["slow_traces"] == 0
+    gs = {}
+    counting = cam.render(world, stats=gs, allow_degenerate=allow_degenerate).data
+    assert st["rays"] == st0["rays"] == gs["rays"] and st["flagged"] == st0["flagged"] == gs["flagged"]
+    return fast, ref_order, counting, st, gs
+
+
+def _same_bits(a, b):
+    return np.array_equal(a.view(np.uint64), b.view(np.uint64))  # NaNs included
+
+
+def _check(rl, oracle, world, p, allow_degenerate=False):
+    cam = rl.Camera(p)
+    fast, ref_order, counting, st, gs = _frames(rl, cam, world, allow_degenerate)
+    assert _same_bits(fast, ref_order) and _same_bits(fast, counting)
+    cs = {}
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    fin = np.isfinite(cpu)
+    assert np.array_equal(np.isfinite(fast), fin)
+    if fin.any():
+        assert np.abs(fast[fin] - cpu[fin]).max() <= 1e-9 * max(1.0, np.abs(cpu[fin]).max())
+    return st
+
+
+def _mats(api):
+    tex = np.zeros(3, dtype=api.TEXTURE)
+    tex["kind"], tex["color"] = api.TEX_SOLID, [(0.9, 0.1, 0.1), (0.1, 0.1, 0.9), (0.5, 0.5, 0.5)]
+    mats = np.zeros(5, dtype=api.MATERIAL)
+    mats[0]["kind"], mats[0]["texture"] = api.MAT_LAMBERTIAN, 0
+    mats[1]["kind"], mats[1]["texture"] = api.MAT_DIFFUSE_LIGHT, 1
+    mats[2]["kind"], mats[2]["albedo"], mats[2]["fuzz"] = api.MAT_METAL, (0.8, 0.8, 0.8), 0.1
+    mats[3]["kind"], mats[3]["ior"] = api.MAT_DIELECTRIC, 1.5
+    mats[4]["kind"], mats[4]["texture"] = api.MAT_LAMBERTIAN, 2
+    return tex, mats
+
+
+def test_fast_traversal_is_the_default_for_the_baseline_scene(rl, oracle):
+    world = rl.World.bouncing_spheres(1)
+    p = world.params
+    p.image_width, p.samples_per_pixel, p.max_depth = 160, 72, 50  # two-launch path
+    st = _check(rl, oracle, world, p)
+    assert st["slow_traces"] * 10_000 < st["rays"]  # the reference-order fallback is the rare path
+
+
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_coincident_spheres_take_the_reference_order_path(rl, oracle, use_bvh):
+    """Identical geometry, different materials: equal roots, the reference's stored order decides (sphere.rs:51-54 accepts t <= closest)."""
+    api = rl.api
+    tex, mats = _mats(api)
+    sph = np.zeros(7, dtype=api.SPHERE)
+    sph["center0"] = [(0, 0, -3), (0, 0, -3), (1.5, 0, -3), (1.5, 0, -3), (-1.5, 0.2, -3.5), (-1.5, 0.2, -3.5), (0, -100.5, -3)]
+    sph["radius"] = [0.5, 0.5, 0.5, 0.5, 0.6, 0.6, 100.0]
+    sph["material"] = [0, 1, 1, 0, 2, 0, 4]
+    world = rl.World.from_spheres(sph, mats, tex, use_bvh)
+    p = rl.CameraParams(aspect_ratio=2.0, image_width=96, samples_per_pixel=4, max_depth=8, vfov=50.0, lookfrom=(0, 0.3, 1), lookat=(0, 0, -3),
+                        background=(0.6, 0.7, 0.9))
+    st = _check(rl, oracle, world, p)
+    assert st["slow_traces"] > 500  # every ray that reaches a coincident pair
+
+
+@pytest.mark.parametrize("n,use_bvh,seed", [(1, True, 1), (2, True, 2), (3, False, 3), (9, True, 4), (37, True, 5), (150, False, 6), (300, True, 7), (511, True, 8)])
+def test_random_worlds_overlapping_moving_every_material(rl, oracle, n, use_bvh, seed):
+    rng = np.random.default_rng(4000 + seed)
+    api = rl.api
+    tex, mats = _mats(api)
+    sph = np.zeros(n, dtype=api.SPHERE)
+    sph["center0"] = rng.uniform(-3, 3, (n, 3))
+    sph["center1"] = sph["center0"] + rng.uniform(0, 0.5, (n, 3))
+    sph["radius"] = rng.uniform(0.05, 0.9, n)  # heavy overlap: many candidates per ray
+    sph["moving"] = rng.integers(0, 2, n)
+    sph["material"] = rng.integers(0, 5, n)
+    world = rl.World.from_spheres(sph, mats, tex, use_bvh)
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=96, samples_per_pixel=6, max_depth=12, vfov=50.0, lookfrom=(0.0, 1.0, 9.0),
+                        lookat=(0.0, 0.0, 0.0), defocus_angle=1.0, focus_dist=9.0, background=(0.5, 0.6, 0.9), seed=seed)
+    st = _check(rl, oracle, world, p)
+    assert st["slow_traces"] * 1000 < st["rays"] + 1000
+
+
+def test_too_many_spheres_or_a_far_camera_fall_back_to_the_reference_order_kernels(rl, oracle):
+    api = rl.api
+    tex, mats = _mats(api)
+    rng = np.random.default_rng(99)
+    n = 512  # one more than the fast structure's entry ids allow
+    sph = np.zeros(n, dtype=api.SPHERE)
+    sph["center0"], sph["radius"], sph["material"] = rng.uniform(-4, 4, (n, 3)), rng.uniform(0.05, 0.3, n), rng.integers(0, 5, n)
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=72, samples_per_pixel=4, max_depth=8, vfov=60.0, lookfrom=(0.0, 1.0, 9.0), lookat=(0, 0, 0))
+    assert _check(rl, oracle, world, p)["slow_traces"] == 0
+    sph = sph[:40].copy()
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    far = rl.CameraParams(aspect_ratio=1.5, image_width=72, samples_per_pixel=4, max_depth=8, vfov=2.0, lookfrom=(0.0, 0.0, 400.0), lookat=(0, 0, 0))
+    assert _check(rl, oracle, world, far)["slow_traces"] == 0  # camera beyond the frame in which the reject-only boxes are rigorous
+
+
+def test_axis_parallel_rays_and_extreme_coordinates(rl, oracle):
+    """Rays with a zero / denormal-scale / huge direction component or a far-away origin are outside the binary32 filter's range:
+    the reference divides by zero there (aabb.rs:143-152) and its NaN / inf semantics must be reproduced, not approximated."""
+    api = rl.api
+    tex, mats = _mats(api)
+    sph = np.zeros(5, dtype=api.SPHERE)
+    sph["center0"] = [(0, 0, -4), (1.0, 0, -4), (-1.0, 0.5, -4), (0, -100.5, -4), (0, 1.0, -5)]
+    sph["radius"] = [0.5, 0.5, 0.5, 100.0, 0.7]
+    sph["material"] = [0, 3, 2, 4, 1]
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=33, samples_per_pixel=4, max_depth=6, vfov=40.0, lookfrom=(0, 0, 1), lookat=(0, 0, -4))
+    cam = rl.Camera(p)
+    # a camera whose every primary ray is exactly axis-parallel: pixel grid steps along x and y only, origin moves with the pixel
+    c = cam.c
+    c.pixel_du[:], c.pixel_dv[:] = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)
+    c.pixel_00[:] = (0.0, 0.0, -1.0)
+    c.lookfrom[:] = (0.0, 0.0, 1.0)
+    c.defocus_angle = 1.0
+    c.defocus_disk_u[:], c.defocus_disk_v[:] = (1.5, 0.0, 0.0), (0.0, 1.5, 0.0)  # origins spread over a disc, d = (-a, -b, -2)... not parallel
+    fast, ref_order, counting, st, gs = _frames(rl, cam, world)
+    assert _same_bits(fast, ref_order) and _same_bits(fast, counting)
+    c.defocus_angle = 0.0  # now every primary ray is (0, 0, -2): two zero components
+    fast, ref_order, counting, st, gs = _frames(rl, cam, world)
+    assert _same_bits(fast, ref_order) and _same_bits(fast, counting)
+    assert st["slow_traces"] >= 33 * 33 * 4  # every primary ray
+    cpu = oracle.rtiow_render(world.desc, c)
+    assert np.abs(fast - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
+
+
+def test_degenerate_sphere_scenes_do_not_use_the_fast_structure(rl, oracle):
+    api = rl.api
+    tex, mats = _mats(api)
+    sph = np.zeros(3, dtype=api.SPHERE)
+    sph["center0"] = [(0, 0, -1), (0.6, 0, -1), (0, -100.5, -1)]
+    sph["radius"] = [0.5, 0.0, 100.0]  # radius 0: (p - c) / r is not finite -> from_normalized would panic (vec3.rs:219)
+    sph["material"] = [0, 0, 4]
+    world = rl.World.from_spheres(sph, mats, tex, False)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=32, samples_per_pixel=2, max_depth=4, lookfrom=(0, 0, 1), lookat=(0, 0, -1))
+    assert _check(rl, oracle, world, p, allow_degenerate=True)["slow_traces"] == 0
+    sph["center0"][:, 0] += 1e12  # unit-sized spheres at x = 1e12: thousands of flagged hits (see test_gpu_timed_kernels)
+    sph["radius"] = [0.5, 0.4, 100.0]
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=32, samples_per_pixel=4, max_depth=4, lookfrom=(1e12, 0, 1), lookat=(1e12, 0, -1))
+    cam = rl.Camera(p)
+    fast, ref_order, counting, st, gs = _frames(rl, cam, world, allow_degenerate=True)
+    assert _same_bits(fast, ref_order) and _same_bits(fast, counting) and gs["flagged"] > 100
+
+
+def test_grazing_rays_over_a_sphere_horizon(rl, oracle):
+    """A camera sitting on a huge sphere looking along its surface: most primary rays graze the ground sphere or pass just above it."""
+    api = rl.api
+    tex, mats = _mats(api)
+    sph = np.zeros(4, dtype=api.SPHERE)
+    sph["center0"] = [(0, -1000, 0), (0, 0.5, -30), (3, 0.2, -20), (-4, 1.0, -40)]
+    sph["radius"] = [1000.0, 0.5, 0.2, 1.0]
+    sph["material"] = [4, 3, 2, 0]
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    p = rl.CameraParams(aspect_ratio=4.0, image_width=256, samples_per_pixel=8, max_depth=10, vfov=3.0, lookfrom=(0, 0.02, 10), lookat=(0, -0.45, -90),
+                        background=(0.6, 0.7, 0.9), seed=5)
+    _check(rl, oracle, world, p)
