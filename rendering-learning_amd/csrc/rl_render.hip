@@ -40,6 +40,7 @@ size_t g_lds_max = 65536;
 int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
 bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
 unsigned long long g_last_slow_traces = 0;
+bool g_fast_debug_stats = false;  // tools only: counting renders run the fast kernel too (counters are then NOT the reference's)
 bool g_fast_traversal = true;  // counter-free renders of LDS-sized sphere scenes use the fast traversal (RL_FAST=0 disables; A/B only)
 
 int set_err(int code, const std::string &m) {
@@ -358,9 +359,14 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
         for (int k = 0; k < 6; k++) H->cops[i].box[k] = (float)gops[i].box[k];
         H->cops[i].w_hit = gops[i].code, H->cops[i].w_miss = gops[i].skip;
       }
-      H->movbits.assign((rt.spheres.size() + 31) / 32 + 1, 0u);
-      for (size_t i = 0; i < rt.spheres.size(); i++)
+      // [one bit per sphere: Center::Moving][one bit per sphere: Metal / Dielectric material (the fast kernel's ST_SHADE2)]
+      const size_t bw = (rt.spheres.size() + 31) / 32 + 1;
+      H->movbits.assign(2 * bw, 0u);
+      for (size_t i = 0; i < rt.spheres.size(); i++) {
         if (desc->spheres[i].moving) H->movbits[i >> 5] |= 1u << (i & 31);
+        uint32_t kind = rt.materials[rt.sphere_material[i]].kind;
+        if (kind == RL_MAT_METAL || kind == RL_MAT_DIELECTRIC) H->movbits[bw + (i >> 5)] |= 1u << (i & 31);
+      }
       H->centry0 = gentry;
       std::memcpy(H->guard_center, frame.center, sizeof frame.center);
       H->guard_reach = frame.reach;
@@ -624,8 +630,8 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   }
   // 1029 = the FAST traversal (ordered binary tree, reject-only boxes, exact re-trace of ambiguous rays): counter-free renders only —
   // its box / sphere test counts are not the reference's, so a render that asks for rl_stats runs the counting kernel (1027)
-  const size_t fast_bytes = ((size_t)P.n_fast_inner * sizeof(FastNode) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const bool fits_fast = fits_compact && H.fast_root != FAST_NONE && !want_stats && (size_t)16 * 1024 * sizeof(unsigned long long) + fast_bytes <= g_lds_max &&
+  const size_t fast_bytes = ((size_t)P.n_fast_inner * sizeof(FastNode) + 2 * (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const bool fits_fast = fits_compact && H.fast_root != FAST_NONE && (!want_stats || g_fast_debug_stats) && (size_t)16 * 1024 * sizeof(unsigned long long) + fast_bytes <= g_lds_max &&
                          g_fast_traversal;
   if (variant == 1029 && (general || !fits_fast)) variant = 0;
   if (variant == 1027 && (general || !fits_compact)) variant = 0;
@@ -689,7 +695,8 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     } else if (variant == 1029) {  // 4 waves per SIMD: rings + fast traversal nodes in LDS, spheres read from L2; never a counting render
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;
-      rc = launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
+      // <.., 4, true> only under rl_debug_fast_stats (tools/sched.py): scheduler occupancy of the fast kernel; its box / sphere counts are its own
+      rc = want_stats ? launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
     } else if (variant == 1027) {  // 4 waves per SIMD: rings + compact guarded ops in LDS, spheres read from L2
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + compact_bytes;
@@ -800,6 +807,7 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
 void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
+void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
 // rays of the render rl_render_status last waited for that the fast traversal re-traced in the reference's order
 unsigned long long rl_debug_slow_traces(void) { return g_last_slow_traces; }
 int rl_debug_has_experimental(void) {

@@ -20,11 +20,15 @@
 // direction component — the lane re-evaluates the reference's exact divisions.  Decisions are
 // therefore bit-identical to the reference (tests assert equal AABB/sphere/ray/RNG-word counters).
 #pragma once
+#include <type_traits>
+
 #include "rl_rtiow_kernel.h"
 
 namespace rl {
 
-enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5 };
+// ST_SHADE2 (fast traversal only): the specular half of SHADE — Metal and Dielectric hits — so that the many Lambertian / miss lanes
+// do not walk through normalize(), Schlick and refract() code they never need
+enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6 };
 
 // two-block ChaCha ring in LDS: 16 u64 slots per lane, slot-major ([slot][lane]) => conflict-free
 template <int NT>
@@ -162,6 +166,28 @@ __device__ __forceinline__ bool aabb_fast32(const float *b, const RayAux32 &ra, 
   return diff > 0.0f;
 }
 
+// Per-ray constants of the FAST traversal's reject-only test, computed in binary32 from the start (no binary64 division):
+//   d32 = RN32(d), inv32 = v_rcp_f32(d32) (<= 1 ulp), o32 = RN32(o), oi32 = RN32(o32 * inv32), u = 2^-24.
+// inv32 = (1/d)(1 + e), |e| <= 3u;  b32 * inv32 is off by <= 4u|b/d| <= 4u(|t| + |o/d|) (the node boxes are stored exactly, rounded
+// OUTWARDS);  oi32 by <= 5u|o/d|;  one more rounding in the fma and the clamp closest32 = RN32(closest): each end of [tmin, tmax] is
+// off by <= 6u|t| + 9u max|o/d|.  A box is therefore CERTAINLY missed when tmin'' - tmax'' > 12u(|tmin''| + |tmax''|) + 24u max|oi32|
+// (the bound for both ends together, plus room for the roundings of this comparison itself).  Rays with a zero, denormal-scale or
+// huge direction component or a far-away origin get slack = +inf: nothing is ever certain for them, and start_ray() sends them
+// to the reference-order fold.
+__device__ __forceinline__ RayAux32 ray_aux32_direct(D3 o, D3 d) {
+  RayAux32 r;
+  float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  r.invx = __builtin_amdgcn_rcpf(dx), r.invy = __builtin_amdgcn_rcpf(dy), r.invz = __builtin_amdgcn_rcpf(dz);
+  r.oix = (float)o.x * r.invx, r.oiy = (float)o.y * r.invy, r.oiz = (float)o.z * r.invz;
+  float m = fmaxf(fmaxf(fabsf(r.oix), fabsf(r.oiy)), fabsf(r.oiz));
+  float imin = fminf(fminf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz)), imax = fmaxf(fmaxf(fabsf(r.invx), fabsf(r.invy)), fabsf(r.invz));
+  float omax = fmaxf(fmaxf(fabsf((float)o.x), fabsf((float)o.y)), fabsf((float)o.z));
+  // every product and sum must stay a NORMAL binary32 number: 1/d within [1e-30, 1e30], |o| and |o/d| <= 1e30 (NaN compares false)
+  bool ok = imin >= 1e-30f && imax <= 1e30f && m <= 1e30f && omax <= 1e30f;
+  r.slack = ok ? m * 1.430511474609375e-06f : __int_as_float(0x7F800000);  // 24u, or +inf: never certain
+  return r;
+}
+
 // LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2,
 // 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2,
 // 4 = FAST traversal (counter-free renders only): P.fast_nodes in LDS — see below
@@ -180,7 +206,8 @@ typedef __attribute__((address_space(3))) const uint32_t LdsU32;
 //   * two roots within 1e-7 relative of each other (exact ties go to the LAST sphere in the reference's order; `tmin < closest`
 //     pruning on the reference's boxes),
 //   * a grazing hit (chord below 1e-6 relative: the reference's unpadded leaf box may or may not be passed),
-//   * a hit whose outward normal trips the from_normalized assert (vec3.rs:219: the panic-site count is order dependent),
+//   * (a hit whose outward normal trips the from_normalized assert, vec3.rs:219, would make the panic-site count order dependent:
+//     scenes in which that assert is reachable do not get a fast structure at all, rl_fast_bvh.cpp normals_safe),
 //   * a ray outside the filter's range (zero / denormal-scale / huge direction component, far-away origin).
 static const uint32_t FAST_SLOW = 0xFFFFFFFFu;  // pc of a lane in ST_LEAF that must re-trace its ray in the reference's order
 
@@ -203,13 +230,10 @@ __device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t pay
   if (1e-10 <= r_l && r_l <= hi) t = r_l;
   else if (1e-10 <= r_u && r_u <= hi) t = r_u;
   else return;
-  D3 p = o + d * t;
-  D3 outward = (p - center) * s.inv_r;
-  double l2 = len2(outward);
-  bool bad_normal = !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
+  // no from_normalized check here: build_fast_bvh only accepts scenes whose frame makes that assert unreachable (GuardFrame::normals_safe)
   bool near_tie = hit_prim != NONE && fabs(t - closest) <= band;
   bool grazing = sq <= 1e-6 * fabs(half_b);
-  amb = amb || bad_normal || near_tie || grazing;
+  amb = amb || near_tie || grazing;
   if (t <= closest) closest = t, hit_prim = payload;
 }
 
@@ -253,7 +277,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   const int tid = threadIdx.x;
   // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
   const size_t bits_words = ((size_t)P.n_spheres + 31) / 32 + 1;
-  const size_t scene_lds = LDS_SCENE == 4   ? (((size_t)P.n_fast_inner * sizeof(FastNode) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
+  const size_t scene_lds = LDS_SCENE == 4   ? (((size_t)P.n_fast_inner * sizeof(FastNode) + 2 * bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
                            : LDS_SCENE == 3 ? (((size_t)P.n_cops * sizeof(CompactOp) + bits_words * sizeof(uint32_t) + 15) & ~(size_t)15)
                            : LDS_SCENE      ? ((size_t)P.n_ops * sizeof(DevOp) + (LDS_SCENE == 1 ? (size_t)P.n_spheres * sizeof(DevSphere) : 0))
                                             : 0;
@@ -267,7 +291,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     uint4 *l = (uint4 *)smem;
     for (uint32_t i = tid; i < P.n_fast_inner * 4u; i += NT) l[i] = g[i];
     uint32_t *bl = (uint32_t *)(smem + (size_t)P.n_fast_inner * sizeof(FastNode));
-    for (uint32_t i = tid; i < (uint32_t)bits_words; i += NT) bl[i] = P.movbits[i];
+    for (uint32_t i = tid; i < 2u * (uint32_t)bits_words; i += NT) bl[i] = P.movbits[i];  // [moving bits][specular-material bits]
     __syncthreads();
     opbase = smem;
     s_bits = bl;
@@ -356,18 +380,29 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     stk4 = (stk4 >> 10) | (FAST_NONE << 22);
     return e;
   };
+  // measured and lost (kept switchable): a separate block for Metal / Dielectric hits shortens SHADE (35.7 % -> 23.3 + 5.2 % of the
+  // wave time) but a sixth state thins every other block (TRAV population 21.2 -> 18.5, LEAF 30.8 -> 27.0): 6.14 -> 5.52 Grays/s
+  constexpr bool SPLIT_SHADE = false;
+  auto shade_state = [&]() -> uint32_t {  // where a finished traversal is shaded
+    if (!SPLIT_SHADE || LDS_SCENE != 4 || hit_prim == NONE) return ST_SHADE;
+    const uint32_t si = hit_prim & SPH_INDEX;
+    return ((s_bits[bits_words + (si >> 5)] >> (si & 31u)) & 1u) ? ST_SHADE2 : ST_SHADE;
+  };
   auto fast_go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), a sphere (LEAF), or nothing left
     if (e == FAST_NONE) {
       if (amb) pc = FAST_SLOW, state = ST_LEAF;
-      else state = ST_SHADE;
+      else state = shade_state();
     } else if (e >= P.n_fast_inner) pc = e, state = ST_LEAF;
     else pc = lds_base + (e << 6), state = ST_TRAV;
   };
   auto start_ray = [&]() {  // o, d set: per-ray constants of the box filter, then the first traversal state
-    ra = ray_aux(o, d);
-    if (!ra.fast_ok) ra.slack = INF;
-    ra32 = ray_aux32(ra);
     closest = INF, hit_prim = NONE;
+    if (LDS_SCENE == 4) ra32 = ray_aux32_direct(o, d);
+    else {
+      ra = ray_aux(o, d);
+      if (!ra.fast_ok) ra.slack = INF;
+      ra32 = ray_aux32(ra);
+    }
     if (LDS_SCENE == 4) {
       stk0 = stk1 = stk2 = stk3 = stk4 = ~0u;
       amb = !(ra32.slack < __int_as_float(0x7F800000));  // outside the binary32 filter's range: the reference's order from the start
@@ -378,30 +413,122 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     }
   };
 
-  unsigned long long sc_exec[6] = {0, 0, 0, 0, 0, 0}, sc_pop[6] = {0, 0, 0, 0, 0, 0}, sc_cyc[6] = {0, 0, 0, 0, 0, 0};
+  // SHADE: miss -> background; hit -> rebuild the HitRecord, scatter, next ray.  MODE 0 = every material (reference-order kernels),
+  // 1 = everything but Metal / Dielectric, 2 = Metal / Dielectric only (ST_SHADE2): the fast kernel's two halves
+  auto shade = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+        bool path_done = false;
+        D3 nd = d;
+        D3 p = o;
+        if (MODE != 2 && hit_prim == NONE) {  // miss -> background (camera.rs:257)
+          sum = sum + thr * ld3(cam.background);
+          path_done = true;
+        } else {
+          uint32_t si = hit_prim & SPH_INDEX;
+          const DevSphere &s = spheres[si];
+          D3 c0 = ld3(s.c0);
+          D3 center = (hit_prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+          p = o + d * closest;
+          D3 outward = (p - center) * s.inv_r;
+          bool front = dot(d, outward) <= 0.0;
+          D3 normal = front ? outward : -outward;
+          // one flattened record per sphere (rl_render.hip flatten_sphere_materials): the material with a Solid texture's
+          // colour inlined, and for a Dielectric the constants 1/ior and Schlick's r0 of both orientations — one load
+          // instead of the sphere -> material -> texture chain, same values bit for bit
+          const DevMaterial &m = P.sphere_flat[si];
+          const uint32_t kind = m.kind & 0xFFu;
+          const bool solid = (m.kind & MAT_TEX_SOLID) != 0u;
+          // shared sub-expressions, evaluated once per block instead of once per material branch (same values, same
+          // RNG order: the unit-sphere draw is the first draw of both Lambertian and Metal scatter)
+          const bool is_lamb = MODE != 2 && kind == RL_MAT_LAMBERTIAN, is_metal = MODE != 1 && kind == RL_MAT_METAL, is_diel = MODE != 1 && kind == RL_MAT_DIELECTRIC;
+          D3 us = d3(0.0, 0.0, 0.0);
+          if (is_lamb | is_metal) us = rng.unit_sphere();
+          D3 reflected = d - normal * (2.0 * dot(d, normal));  // material.rs reflect(): used by Metal
+          D3 vin = is_metal ? reflected : d;
+          D3 vn = vin;
+          double m2 = len2(vin);
+          if (is_metal | is_diel) vn = div_s(vin, sqrt(m2));  // normalize(): vec3.rs:56
+          if (is_lamb) {
+            D3 dir = normal + us;
+            bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
+            nd = near_zero ? normal : dir;
+            thr = thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
+          } else if (is_metal) {
+            nd = vn + us * m.fuzz;
+            if (!(dot(nd, normal) > 0.0)) path_done = true;  // absorbed
+            else thr = thr * ld3(m.albedo);
+          } else if (is_diel) {
+            double ri = front ? m.albedo[0] : m.ior;  // albedo[0] = 1.0 / ior
+            D3 ud = vn;
+            if (approx_eq_eps(m2, 0.0, 1e-16)) {
+              c_flag++;
+              ud = d;
+            }
+            double cos_theta = fmin(dot(-ud, normal), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool reflect = ri * sin_theta > 1.0;
+            if (!reflect) {
+              double r0 = front ? m.albedo[1] : m.albedo[2];  // ((1 - ri) / (1 + ri))^2 for ri = 1/ior and ri = ior
+              double xx = 1.0 - cos_theta;
+              double x2 = xx * xx;
+              double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
+              reflect = refl > rng.gen_f64();
+            }
+            if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
+            else {
+              D3 perp = (ud + normal * cos_theta) * ri;
+              D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
+              nd = perp + par;
+            }
+          } else if (MODE != 2 && kind == RL_MAT_DIFFUSE_LIGHT) {
+            sum = sum + thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
+            path_done = true;
+          } else {
+            path_done = true;  // Flat
+          }
+        }
+        if (!path_done) {
+          depth--;
+          if (depth == 0) path_done = true;  // ray_color(.., 0) = black
+        }
+        if (path_done) {
+          n++;
+          state = ST_GEN;
+        } else {
+          c_rays++;
+          pix_rays++;
+          o = p;
+          d = nd;
+          start_ray();
+        }
+  };
+
+  unsigned long long sc_exec[7] = {0, 0, 0, 0, 0, 0, 0}, sc_pop[7] = {0, 0, 0, 0, 0, 0, 0}, sc_cyc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (;;) {
     // a finished traversal goes to SHADE; lanes reading from their newest ChaCha block top the ring up first
-    if (state == ST_SHADE && rng.low()) state = ST_FILL;
+    if ((state == ST_SHADE || (SPLIT_SHADE && LDS_SCENE == 4 && state == ST_SHADE2)) && rng.low()) state = ST_FILL;
     // ---- wave scheduler: run the state with the most lanes in it (ties -> TRAV, SHADE, FILL, GEN)
     int n_trav = __popcll(__ballot(state == ST_TRAV));
     int n_shade = __popcll(__ballot(state == ST_SHADE));
     int n_fill = __popcll(__ballot(state == ST_FILL));
     int n_gen = __popcll(__ballot(state == ST_GEN));
     int n_leaf = __popcll(__ballot(state == ST_LEAF));
-    if ((n_trav | n_shade | n_fill | n_gen | n_leaf) == 0) break;
+    int n_shade2 = SPLIT_SHADE && LDS_SCENE == 4 ? __popcll(__ballot(state == ST_SHADE2)) : 0;
+    if ((n_trav | n_shade | n_fill | n_gen | n_leaf | n_shade2) == 0) break;
     uint32_t pick = ST_TRAV;
     int best = n_trav;
     if (n_leaf > best) pick = ST_LEAF, best = n_leaf;
     if (n_shade > best) pick = ST_SHADE, best = n_shade;
     if (n_fill > best) pick = ST_FILL, best = n_fill;
     if (n_gen > best) pick = ST_GEN, best = n_gen;
+    if (SPLIT_SHADE && LDS_SCENE == 4 && n_shade2 > best) pick = ST_SHADE2, best = n_shade2;
 
     unsigned long long t_begin = 0;
     if (STATS) {  // debug (tools/sched.py): block executions, lanes served and shader cycles per state, per wave
       t_begin = __builtin_readcyclecounter();
       if (pick != ST_TRAV) {
 #pragma unroll
-        for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 7; k++)
           if (pick == (uint32_t)k) sc_exec[k]++, sc_pop[k] += (unsigned)best;
       }
     }
@@ -430,9 +557,10 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
               tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
               float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), c32);
               float diff = tmax - tmin;
-              float thresh = fmaf(tmin + fabsf(tmax), 4.76837158203125e-07f, ra32.slack);  // 8u(|tmin|+|tmax|) + slack (aabb_fast32)
+              float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
               return diff < -thresh;  // certainly tmin > tmax; false for NaN arithmetic: visit
             };
+            if (STATS) c_nodes += 2;  // debug instantiation only (rl_debug_fast_stats): the fast structure's own tests, not the reference's
             float tA, tB;
             const bool hitA = !missed(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tA);
             const bool hitB = !missed(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tB);
@@ -483,10 +611,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           if (pc == FAST_SLOW) {  // rare: the answer may depend on the visiting order -> the reference's own fold
             c_flag += fast_slow_trace(P.ops, spheres, o, d, time, closest, hit_prim);
             c_slow++;
-            state = ST_SHADE;
+            state = shade_state();
           } else {
             const uint32_t sidx = pc - P.n_fast_inner;
             const uint32_t payload = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u);
+            if (STATS) c_sph++;
             fast_sphere_hit(spheres[sidx], payload, o, d, time, closest, hit_prim, amb);
             fast_go(fast_pop());
           }
@@ -515,7 +644,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     } else if (pick == ST_FILL) {
       if (state == ST_FILL) {
         rng.top_up();
-        state = ST_SHADE;
+        state = shade_state();
       }
     } else if (pick == ST_GEN) {
       if (state == ST_GEN) {
@@ -590,105 +719,25 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           }
         }
       }
+    } else if (SPLIT_SHADE && pick == ST_SHADE2) {
+      if (state == ST_SHADE2) shade(std::integral_constant<int, 2>{});
     } else {  // ST_SHADE
       if (state == ST_SHADE) {
-        bool path_done = false;
-        D3 nd = d;
-        D3 p = o;
-        if (hit_prim == NONE) {  // miss -> background (camera.rs:257)
-          sum = sum + thr * ld3(cam.background);
-          path_done = true;
-        } else {
-          uint32_t si = hit_prim & SPH_INDEX;
-          const DevSphere &s = spheres[si];
-          D3 c0 = ld3(s.c0);
-          D3 center = (hit_prim & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
-          p = o + d * closest;
-          D3 outward = (p - center) * s.inv_r;
-          bool front = dot(d, outward) <= 0.0;
-          D3 normal = front ? outward : -outward;
-          // one flattened record per sphere (rl_render.hip flatten_sphere_materials): the material with a Solid texture's
-          // colour inlined, and for a Dielectric the constants 1/ior and Schlick's r0 of both orientations — one load
-          // instead of the sphere -> material -> texture chain, same values bit for bit
-          const DevMaterial &m = P.sphere_flat[si];
-          const uint32_t kind = m.kind & 0xFFu;
-          const bool solid = (m.kind & MAT_TEX_SOLID) != 0u;
-          // shared sub-expressions, evaluated once per block instead of once per material branch (same values, same
-          // RNG order: the unit-sphere draw is the first draw of both Lambertian and Metal scatter)
-          const bool is_lamb = kind == RL_MAT_LAMBERTIAN, is_metal = kind == RL_MAT_METAL, is_diel = kind == RL_MAT_DIELECTRIC;
-          D3 us = d3(0.0, 0.0, 0.0);
-          if (is_lamb | is_metal) us = rng.unit_sphere();
-          D3 reflected = d - normal * (2.0 * dot(d, normal));  // material.rs reflect(): used by Metal
-          D3 vin = is_metal ? reflected : d;
-          D3 vn = vin;
-          double m2 = len2(vin);
-          if (is_metal | is_diel) vn = div_s(vin, sqrt(m2));  // normalize(): vec3.rs:56
-          if (is_lamb) {
-            D3 dir = normal + us;
-            bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
-            nd = near_zero ? normal : dir;
-            thr = thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
-          } else if (is_metal) {
-            nd = vn + us * m.fuzz;
-            if (!(dot(nd, normal) > 0.0)) path_done = true;  // absorbed
-            else thr = thr * ld3(m.albedo);
-          } else if (is_diel) {
-            double ri = front ? m.albedo[0] : m.ior;  // albedo[0] = 1.0 / ior
-            D3 ud = vn;
-            if (approx_eq_eps(m2, 0.0, 1e-16)) {
-              c_flag++;
-              ud = d;
-            }
-            double cos_theta = fmin(dot(-ud, normal), 1.0);
-            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-            bool reflect = ri * sin_theta > 1.0;
-            if (!reflect) {
-              double r0 = front ? m.albedo[1] : m.albedo[2];  // ((1 - ri) / (1 + ri))^2 for ri = 1/ior and ri = ior
-              double xx = 1.0 - cos_theta;
-              double x2 = xx * xx;
-              double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
-              reflect = refl > rng.gen_f64();
-            }
-            if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
-            else {
-              D3 perp = (ud + normal * cos_theta) * ri;
-              D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
-              nd = perp + par;
-            }
-          } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
-            sum = sum + thr * (solid ? ld3(m.albedo) : texture_value(P, m.texture, 0.0, 0.0, p));
-            path_done = true;
-          } else {
-            path_done = true;  // Flat
-          }
-        }
-        if (!path_done) {
-          depth--;
-          if (depth == 0) path_done = true;  // ray_color(.., 0) = black
-        }
-        if (path_done) {
-          n++;
-          state = ST_GEN;
-        } else {
-          c_rays++;
-          pix_rays++;
-          o = p;
-          d = nd;
-          start_ray();
-        }
+        if (SPLIT_SHADE && LDS_SCENE == 4) shade(std::integral_constant<int, 1>{});
+        else shade(std::integral_constant<int, 0>{});
       }
     }
     if (STATS) {
       unsigned long long dt = __builtin_readcyclecounter() - t_begin;
 #pragma unroll
-      for (int k = 0; k < 6; k++)
+      for (int k = 0; k < 7; k++)
         if (pick == (uint32_t)k) sc_cyc[k] += dt;
     }
   }
   if (STATS && (tid & 63) == 0) {
     unsigned long long *sched = P.stats + 8;  // [3*s] executions, [3*s+1] lanes served, [3*s+2] cycles
 #pragma unroll
-    for (int s = 0; s < 6; s++) {
+    for (int s = 0; s < 7; s++) {
       atomicAdd(&sched[3 * s], sc_exec[s]);
       atomicAdd(&sched[3 * s + 1], sc_pop[s]);
       atomicAdd(&sched[3 * s + 2], sc_cyc[s]);
