@@ -391,7 +391,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   auto fast_go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), a sphere (LEAF), or nothing left
     if (e == FAST_NONE) {
       if (amb) pc = FAST_SLOW, state = ST_LEAF;
-      else state = shade_state();
+      else if (hit_prim == NONE) {  // a miss needs no SHADE visit: background (camera.rs:257), sample done (+10 %)
+        sum = sum + thr * ld3(P.cam.background);
+        n++;
+        state = ST_GEN;
+      } else state = shade_state();
     } else if (e >= P.n_fast_inner) pc = e, state = ST_LEAF;
     else pc = lds_base + (e << 6), state = ST_TRAV;
   };
