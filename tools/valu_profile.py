@@ -40,7 +40,7 @@ typed = ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F3
          "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT64"]
 out = {
     "workload_scene": "bouncing_spheres(1)", "width": W, "height": H, "depth": depth, "pmc_spp": spp, "pmc_rays": rays,
-    "kernel": "rtiow_wave_kernel<1024,3,false>",
+    "kernel": "rtiow_wave_kernel<1024,4,false>",
     "valu_wave_insts_per_ray": c["SQ_INSTS_VALU"] / rays,
     "class_wave_insts_per_ray": {k[len("SQ_INSTS_VALU_"):]: c[k] / rays for k in typed} | {"OTHER_32": (c["SQ_INSTS_VALU"] - sum(c[k] for k in typed)) / rays},
     "valu_issue_slots_per_ray": slots / rays,
