@@ -183,4 +183,336 @@ bool build_fast_bvh(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, const 
   return true;
 }
 
+
+// =====================================================================================================================
+// General scenes: world-space tree over primitive occurrences.
+//
+// The same argument as above carries over with three additions.
+//  * Instances.  The reference evaluates a primitive under Translate / Transform scopes in OBJECT space (transform.rs:143-164: the
+//    ray is transformed, t is not), so the device does exactly that for every candidate (replay of the PUSH chain, then the
+//    reference's Sphere::hit / Plane::hit_ab arithmetic); only the reject-only boxes live in world space: bounds of the
+//    primitive's transformed vertices (sphere: of the eight corners of its object-space box), grown by a relative 1e-9 of the
+//    coordinates involved plus, for spheres, guard_pad mapped through the chain's norm bounds.
+//  * Planar hits near an edge (barycentric within 1e-9 of 0 / 1) join the order-sensitive cases: the reference's own leaf box is
+//    the exact bound of the vertices, so an edge-grazing hit may or may not pass it.
+//  * The panic sites that depend on WHICH hits are accepted (sphere from_normalized, interpolated triangle normal ~ 0, instance
+//    normal ~ 0) must be unreachable for every ray that relies on pruning: spheres bound the ray origins for which that holds (r_safe,
+//    checked per ray in binary32); a ray that starts farther away — e.g. inside a huge ground sphere after a self-intersection at
+//    t ~ 1e-10, which the reference produces too — widens every box by the padding its distance needs, does not prune by the closest
+//    hit, and is re-traced in the reference's order as soon as it numerically touches a sphere from more than ~5e4 radii away.
+//    Triangles with vertex normals need pairwise positive dot products, matrices a bounded norm.
+namespace {
+
+struct Chain {          // accumulated bounds of one PUSH chain
+  std::vector<uint32_t> pushes;  // outermost first
+  double ninv = 1.0;    // bound on |M^-1 v| / |v| through the chain (world -> object)
+  double shift = 0.0;   // bound on the translation part (world -> object), in object units
+};
+
+double mat_norm_inf(const double *m) {
+  double n = 0.0;
+  for (int r = 0; r < 3; r++) n = std::fmax(n, std::fabs(m[3 * r]) + std::fabs(m[3 * r + 1]) + std::fabs(m[3 * r + 2]));
+  return n;
+}
+
+void to_world(const rl_rtiow_scene_desc &d, const std::vector<DevOp> &ops, const std::vector<uint32_t> &pushes, double p[3]) {
+  for (size_t k = pushes.size(); k-- > 0;) {  // innermost first, as the reference's recursion unwinds
+    const DevOp &op = ops[pushes[k]];
+    if ((op.code & 0xFFu) == OP_PUSH_TRANSLATE) {
+      const double *off = d.translates[op.a].offset;
+      for (int i = 0; i < 3; i++) p[i] += off[i];
+    } else {
+      const double *m = d.transforms[op.a].m;
+      double q[3];
+      for (int r = 0; r < 3; r++) q[r] = m[3 * r] * p[0] + m[3 * r + 1] * p[1] + m[3 * r + 2] * p[2];
+      p[0] = q[0], p[1] = q[1], p[2] = q[2];
+    }
+  }
+}
+
+struct GItem {
+  FastItem it;
+  Box box;       // world-space bounds (unpadded)
+  double r = 0;  // spheres: radius; else 0
+  double ninv = 1.0, shift = 0.0, cobj = 0.0;  // spheres: chain bounds, |object-space centre|_inf
+};
+
+}  // namespace
+
+bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out) {
+  out = FastGeneral{};
+  const std::vector<DevOp> &ops = rt.ops;
+  // ---- matrices: finite, bounded norm (an instance normal M^-T n of a unit n then has |.|^2 >= 1 / (3 |M|_inf^2) >> 1e-16)
+  for (uint32_t i = 0; i < d.n_transforms; i++) {
+    const rl_transform &t = d.transforms[i];
+    for (int k = 0; k < 9; k++)
+      if (!std::isfinite(t.m[k]) || !std::isfinite(t.inv[k]) || !std::isfinite(t.inv_t[k])) return false;
+    if (!(mat_norm_inf(t.m) <= 1e5 && mat_norm_inf(t.inv) <= 1e5)) return false;
+  }
+  for (uint32_t i = 0; i < d.n_translates; i++)
+    for (int k = 0; k < 3; k++)
+      if (!(std::fabs(d.translates[i].offset[k]) <= 1e30)) return false;
+  // ---- items = primitive occurrences, in program order
+  std::vector<GItem> items;
+  std::vector<uint32_t> pushes;
+  auto chain_of = [&](GItem &g) {
+    g.it.chain = pushes.empty() ? NONE : pushes.back();
+    double ninv = 1.0, shift = 0.0;
+    for (uint32_t pc : pushes) {  // outermost first: o' = M^-1 o  or  o' = o - offset
+      const DevOp &op = ops[pc];
+      if ((op.code & 0xFFu) == OP_PUSH_TRANSLATE) {
+        const double *off = d.translates[op.a].offset;
+        shift += std::fmax(std::fabs(off[0]), std::fmax(std::fabs(off[1]), std::fabs(off[2]))) * 1.7320508075688772;
+      } else {
+        double n = mat_norm_inf(d.transforms[op.a].inv) * 1.7320508075688772;  // 2-norm <= sqrt(3) inf-norm
+        ninv *= n, shift *= n;
+      }
+    }
+    g.ninv = ninv, g.shift = shift;
+  };
+  auto add_points = [&](GItem &g, const double (*pts)[3], int n) {
+    g.box = EMPTY;
+    for (int k = 0; k < n; k++) {
+      double p[3] = {pts[k][0], pts[k][1], pts[k][2]};
+      to_world(d, ops, pushes, p);
+      for (int ax = 0; ax < 3; ax++) g.box.lo[ax] = std::fmin(g.box.lo[ax], p[ax]), g.box.hi[ax] = std::fmax(g.box.hi[ax], p[ax]);
+    }
+  };
+  auto add_sphere = [&](uint32_t payload, uint32_t pc) -> bool {
+    const rl_sphere &sp = d.spheres[payload & SPH_INDEX];
+    double r = std::fabs(sp.radius);
+    if (!(std::isfinite(sp.radius) && r > 0.0)) return false;
+    GItem g;
+    g.it.kind = 0, g.it.payload = payload, g.it.op_pc = pc;
+    chain_of(g);
+    double lo[3], hi[3], cmax = 0.0;
+    for (int ax = 0; ax < 3; ax++) {
+      double c0 = sp.center0[ax], c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
+      if (!std::isfinite(c0) || !std::isfinite(c1)) return false;
+      lo[ax] = std::fmin(c0, c1) - r, hi[ax] = std::fmax(c0, c1) + r;
+      cmax = std::fmax(cmax, std::fmax(std::fabs(c0), std::fabs(c1)));
+    }
+    double pts[8][3];
+    for (int k = 0; k < 8; k++)
+      for (int ax = 0; ax < 3; ax++) pts[k][ax] = ((k >> ax) & 1) ? hi[ax] : lo[ax];
+    add_points(g, pts, 8);
+    g.r = r, g.cobj = cmax;
+    items.push_back(g);
+    return true;
+  };
+  auto add_planar = [&](uint32_t idx, uint32_t pc) -> bool {
+    const rl_planar &pl = d.planars[idx];
+    if (pl.kind != RL_PLANAR_QUAD && pl.kind != RL_PLANAR_TRIANGLE) return false;  // an unbounded Plane has no box
+    GItem g;
+    g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc;
+    chain_of(g);
+    double pts[4][3];
+    for (int ax = 0; ax < 3; ax++) {
+      pts[0][ax] = pl.q[ax], pts[1][ax] = pl.q[ax] + pl.u[ax], pts[2][ax] = pl.q[ax] + pl.v[ax], pts[3][ax] = pl.q[ax] + pl.u[ax] + pl.v[ax];
+      if (!std::isfinite(pts[3][ax])) return false;
+    }
+    add_points(g, pts, pl.kind == RL_PLANAR_QUAD ? 4 : 3);
+    if (pl.kind == RL_PLANAR_TRIANGLE && pl.has_normals) {  // triangle.rs:78-83: unit(n2 a + n3 b + n1 (1-a-b)) must not come near zero
+      const double *n = pl.normals;
+      for (int i = 0; i < 3; i++) {
+        double l2 = n[3 * i] * n[3 * i] + n[3 * i + 1] * n[3 * i + 1] + n[3 * i + 2] * n[3 * i + 2];
+        if (!(l2 >= 1e-6 && l2 <= 1e6)) return false;
+        for (int j = i + 1; j < 3; j++)
+          if (!(n[3 * i] * n[3 * j] + n[3 * i + 1] * n[3 * j + 1] + n[3 * i + 2] * n[3 * j + 2] > 0.0)) return false;
+      }
+    }
+    items.push_back(g);
+    return true;
+  };
+  for (uint32_t pc = 0; pc < ops.size(); pc++) {
+    const DevOp &op = ops[pc];
+    uint32_t kind = op.code & 0xFFu;
+    bool ok = true;
+    if (kind == OP_PUSH_TRANSLATE || kind == OP_PUSH_TRANSFORM) pushes.push_back(pc);
+    else if (kind == OP_POP_TRANSLATE || kind == OP_POP_TRANSFORM) pushes.pop_back();
+    else if (kind == OP_SPHERE) ok = add_sphere(op.a, pc);
+    else if (kind == OP_PLANAR) ok = add_planar(op.a, pc);
+    else if (kind == OP_BOX_SPH) ok = add_sphere(op.a, pc) && (op.b == NONE || add_sphere(op.b, pc));
+    else if (kind == OP_BOX_PLANAR) ok = add_planar(op.a, pc) && (op.b == NONE || add_planar(op.b, pc));
+    if (!ok) return false;
+  }
+  const size_t n = items.size();
+  if (n >= 0x7FFFFFF0u) return false;
+  if (n == 0) {
+    out.ok = true, out.root = NONE, out.r_safe = 1e30f;
+    return true;
+  }
+  for (const GItem &g : items)
+    for (int ax = 0; ax < 3; ax++)
+      if (!(std::fabs(g.box.lo[ax]) <= 1e30 && std::fabs(g.box.hi[ax]) <= 1e30)) return false;
+  // ---- frame: centre = mean of the item centres; r_safe = (nearly) the largest radius for which every sphere's padding and
+  // normal-check bounds hold for ray origins within r_safe of the centre
+  double c[3] = {0, 0, 0};
+  for (const GItem &g : items)
+    for (int ax = 0; ax < 3; ax++) c[ax] += 0.5 * (g.box.lo[ax] + g.box.hi[ax]) / (double)n;
+  const double u = 1.1102230246251565e-16;
+  auto far_of = [&](const GItem &g) {  // farthest point of the item's world box from the centre
+    double s = 0.0;
+    for (int ax = 0; ax < 3; ax++) {
+      double m = std::fmax(std::fabs(g.box.lo[ax] - c[ax]), std::fabs(g.box.hi[ax] - c[ax]));
+      s += m * m;
+    }
+    return std::sqrt(s);
+  };
+  auto sphere_bounds = [&](const GItem &g, double R, double &Lobj, double &Mobj) {
+    Lobj = (g.ninv * (R + far_of(g)) + g.shift) * 1.001 + 2.0 * g.r;  // |o' - c| + r in object space, origin within R (Euclidean) of the centre
+    Mobj = g.cobj + g.r + Lobj;
+  };
+  // Sphere::hit's outward normal misses unit length by at most 24u ((|oc| + r) / r)^2 (residual of the rounded root in the rounded
+  // quadratic) + 3.5u (|oc| + r + M) / r (rounding of p = o + t d) + 8u (the evaluation itself); the assert fires beyond 1e-5
+  auto admissible = [&](double R) {
+    for (const GItem &g : items) {
+      if (g.it.kind != 0) continue;
+      double L, M;
+      sphere_bounds(g, R, L, M);
+      if (!(32.0 * u * (L / g.r) * (L / g.r) + 8.0 * u * (M + L) / g.r + 16.0 * u <= 1e-5)) return false;
+    }
+    return true;
+  };
+  double r_safe = 0.0;
+  for (int e = 60; e >= -20 && r_safe == 0.0; e--)
+    if (admissible(std::ldexp(1.0, e))) r_safe = std::ldexp(1.0, e);
+  if (r_safe == 0.0) return false;
+  for (double step = 0.5 * r_safe; step > 1e-3 * r_safe; step *= 0.5)  // refine between r_safe and 2 r_safe
+    if (admissible(r_safe + step)) r_safe += step;
+  r_safe = std::fmin(r_safe, 1e18);
+  // ---- padded binary32 boxes
+  std::vector<Box> pb(n);
+  double cabs = std::fmax(std::fabs(c[0]), std::fmax(std::fabs(c[1]), std::fabs(c[2])));
+  for (size_t i = 0; i < n; i++) {
+    const GItem &g = items[i];
+    double extra = 0.0;
+    if (g.it.kind == 0) {  // object-space guard pad, mapped to world space by the forward norm bound (<= 1e5 * sqrt(3) per level, folded into ninv's reciprocal is not available: use the world box growth factor)
+      double L, M;
+      sphere_bounds(g, r_safe, L, M);
+      double pad_obj = 8.0 * (8.0 * u * L * L + 2.0 * u * M * L) / g.r;
+      double ext = 0.0;
+      for (int ax = 0; ax < 3; ax++) ext = std::fmax(ext, g.box.hi[ax] - g.box.lo[ax]);
+      extra = pad_obj * (ext / (2.0 * g.r)) * 1.7320508075688772;  // world extent / object diameter bounds the chain's stretch
+    }
+    for (int ax = 0; ax < 3; ax++) {
+      double lo = g.box.lo[ax], hi = g.box.hi[ax];
+      double pad = 1e-9 * (std::fabs(lo) + std::fabs(hi) + (hi - lo) + cabs + far_of(g)) + extra + 1e-300;
+      pb[i].lo[ax] = lo - pad, pb[i].hi[ax] = hi + pad;
+    }
+  }
+  // ---- binned SAH build (16 bins per axis on the box centres), leaf = one item, depth <= FASTG_MAX_DEPTH
+  out.items.resize(n);
+  for (size_t i = 0; i < n; i++) out.items[i] = items[i].it;
+  std::vector<uint32_t> ids(n);
+  std::iota(ids.begin(), ids.end(), 0u);
+  out.nodes.reserve(n);
+  auto put = [&](FastNodeG &nd, int side, const Box &b) {
+    for (int ax = 0; ax < 3; ax++) nd.box[side][2 * ax] = round_down(b.lo[ax]), nd.box[side][2 * ax + 1] = round_up(b.hi[ax]);
+  };
+  std::function<uint32_t(size_t, size_t, uint32_t, Box &)> build = [&](size_t lo, size_t hi, uint32_t budget, Box &ob) -> uint32_t {
+    const size_t m = hi - lo;
+    if (m == 1) {
+      ob = pb[ids[lo]];
+      return FASTG_LEAF | ids[lo];
+    }
+    const uint32_t self = (uint32_t)out.nodes.size();
+    out.nodes.push_back(FastNodeG{});
+    uint32_t need = 0;
+    while (((size_t)1 << need) < m) need++;
+    Box cb = EMPTY;  // bounds of the box centres
+    for (size_t i = lo; i < hi; i++) {
+      const Box &b = pb[ids[i]];
+      for (int ax = 0; ax < 3; ax++) {
+        double ctr = 0.5 * (b.lo[ax] + b.hi[ax]);
+        cb.lo[ax] = std::fmin(cb.lo[ax], ctr), cb.hi[ax] = std::fmax(cb.hi[ax], ctr);
+      }
+    }
+    size_t split = lo + m / 2;
+    bool done = false;
+    if (need < budget) {
+      const int NB = 16;
+      const size_t cap = budget - 1 >= 63 ? (size_t)-1 : ((size_t)1 << (budget - 1));
+      double best = INFINITY;
+      int best_ax = -1, best_bin = -1;
+      for (int ax = 0; ax < 3; ax++) {
+        double w = cb.hi[ax] - cb.lo[ax];
+        if (!(w > 0.0)) continue;
+        Box bins[NB];
+        size_t cnt[NB];
+        for (int b = 0; b < NB; b++) bins[b] = EMPTY, cnt[b] = 0;
+        double scale = (double)NB / w;
+        for (size_t i = lo; i < hi; i++) {
+          const Box &b = pb[ids[i]];
+          int k = (int)((0.5 * (b.lo[ax] + b.hi[ax]) - cb.lo[ax]) * scale);
+          k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+          bins[k].grow(b), cnt[k]++;
+        }
+        double la[NB];
+        size_t lc[NB];
+        Box acc = EMPTY;
+        size_t c0 = 0;
+        for (int b = 0; b < NB - 1; b++) acc.grow(bins[b]), c0 += cnt[b], la[b] = c0 ? acc.area() * (double)c0 : 0.0, lc[b] = c0;
+        acc = EMPTY, c0 = 0;
+        for (int b = NB - 1; b >= 1; b--) {
+          acc.grow(bins[b]), c0 += cnt[b];
+          size_t left = lc[b - 1];
+          if (left == 0 || c0 == 0 || left > cap || c0 > cap) continue;
+          double cost = la[b - 1] + acc.area() * (double)c0;
+          if (cost < best) best = cost, best_ax = ax, best_bin = b;
+        }
+      }
+      if (best_ax >= 0) {
+        double w = cb.hi[best_ax] - cb.lo[best_ax], scale = 16.0 / w;
+        auto mid = std::partition(ids.begin() + (long)lo, ids.begin() + (long)hi, [&](uint32_t id) {
+          const Box &b = pb[id];
+          int k = (int)((0.5 * (b.lo[best_ax] + b.hi[best_ax]) - cb.lo[best_ax]) * scale);
+          k = k < 0 ? 0 : (k >= 16 ? 15 : k);
+          return k < best_bin;
+        });
+        split = (size_t)(mid - ids.begin());
+        done = split > lo && split < hi;
+      }
+    }
+    if (!done) {  // no slack left for the heuristic (or all centres equal): median split along the widest axis of the centres
+      int ax = 0;
+      double e[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+      ax = e[0] >= e[1] ? (e[0] >= e[2] ? 0 : 2) : (e[1] >= e[2] ? 1 : 2);
+      split = lo + m / 2;
+      std::nth_element(ids.begin() + (long)lo, ids.begin() + (long)split, ids.begin() + (long)hi,
+                       [&](uint32_t a, uint32_t b) { return pb[a].lo[ax] + pb[a].hi[ax] < pb[b].lo[ax] + pb[b].hi[ax]; });
+    }
+    Box ba, bb;
+    uint32_t ea = build(lo, split, budget - 1, ba);
+    uint32_t eb = build(split, hi, budget - 1, bb);
+    FastNodeG &nd = out.nodes[self];
+    put(nd, 0, ba), put(nd, 1, bb);
+    nd.child[0] = ea, nd.child[1] = eb;
+    ob = ba;
+    ob.grow(bb);
+    return self;
+  };
+  if (n == 1) out.root = FASTG_LEAF | 0u;  // a single occurrence: rays start in LEAF, no node at all
+  else {
+    Box all;
+    out.root = build(0, n, FASTG_MAX_DEPTH, all);
+  }
+  // rays from outside r_safe: guard_pad's bound 8 (8u L^2 + 2u M L) / r with L = |oc| <= distance + radius and M <= L + |centre|, for the
+  // smallest sphere; planars need far less (a relative 1e-15 of the coordinates), so one constant serves all items
+  {
+    double rmin = INFINITY, radius = 0.0;
+    for (const GItem &g : items) {
+      radius = std::fmax(radius, far_of(g));
+      if (g.it.kind == 0) rmin = std::fmin(rmin, g.r / g.ninv);  // object-space pad seen from world space: conservative through the chain norms
+    }
+    if (!(rmin < INFINITY)) rmin = 1.0;
+    out.radius = round_up(radius + cabs);
+    out.pad_k = round_up(8.0 * (8.0 * u + 2.0 * u) / rmin * 1.5 + 1e-12);
+  }
+  for (int ax = 0; ax < 3; ax++) out.center[ax] = (float)c[ax];
+  out.r_safe = round_down(r_safe * 0.999 - 1e-6 * cabs);  // the device compares binary32 roundings of o and centre
+  out.ok = out.r_safe > 0.0f;
+  return out.ok;
+}
+
 }  // namespace rl

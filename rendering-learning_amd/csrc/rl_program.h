@@ -124,6 +124,34 @@ double guard_pad(const GuardFrame &f, double radius);  // how far outside a sphe
 // degenerate spheres, spheres referenced more than once or not at all...).  root_entry: entry id a new ray starts at.
 bool build_fast_bvh(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, const GuardFrame &f, std::vector<FastNode> &nodes, uint32_t &root_entry);
 
+// ---- fast traversal structure for GENERAL scenes (planars, instances, any number of primitives; rl_fast_bvh.cpp, rl_rtiow_fastgen.h):
+// a surface-area-heuristic binary tree in WORLD space over the primitive OCCURRENCES of the threaded program (a primitive under a
+// Translate / Transform chain = one item per occurrence), boxes reject-only, nodes and items read from HBM / L2 / Infinity Cache.
+static const uint32_t FASTG_LEAF = 0x80000000u;  // child / entry: bit 31 set -> item index, else inner node index
+static const uint32_t FASTG_MAX_DEPTH = 40;      // the per-lane LDS stack holds 40 entries
+struct alignas(16) FastNodeG {
+  float box[2][6];    // [child][x.min, x.max, y.min, y.max, z.min, z.max], rounded outwards
+  uint32_t child[2];
+  uint32_t pad[2];
+};
+static_assert(sizeof(FastNodeG) == 64, "FastNodeG must be 64 B");
+struct alignas(16) FastItem {
+  uint32_t kind;     // 0 sphere, 1 planar
+  uint32_t payload;  // sphere payload (index | SPH_MOVING | SPH_UV) or planar index
+  uint32_t chain;    // pc of the innermost PUSH op around the primitive (NONE: world space); ops[pc].b = the next one outwards
+  uint32_t op_pc;    // the op that holds the primitive in the reference's program
+};
+struct FastGeneral {
+  std::vector<FastNodeG> nodes;
+  std::vector<FastItem> items;
+  uint32_t root = NONE;      // entry a new ray starts at (NONE: nothing to hit)
+  float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
+  float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)
+  float radius = 0, pad_k = 0;  // ... box growth for those rays = pad_k * (distance to centre + radius)^2 (world units)
+  bool ok = false;
+};
+bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out);
+
 // Returns RL_OK or RL_E_INVALID (err filled).
 int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &out, std::string &err);
 

@@ -21,6 +21,7 @@
 #include "rl_rtiow_general.h"
 #include "rl_rtiow_wave.h"
 #include "rl_rtiow_wave_general.h"
+#include "rl_rtiow_fastgen.h"
 #ifdef RL_EXPERIMENTAL  // the measured-and-lost restructurings: only in librl_render_exp.so, never in the product library
 #include "experimental/rl_rtiow_pool.h"
 #include "experimental/rl_rtiow_wave2.h"
@@ -193,7 +194,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -373,6 +374,9 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
     }
     // the fast traversal structure of the timed (counter-free) kernel: ordered binary tree, reject-only boxes (rl_fast_bvh.cpp)
     if (!H->cops.empty() && !build_fast_bvh(*desc, rt, frame, H->fast_nodes, H->fast_root)) H->fast_nodes.clear(), H->fast_root = FAST_NONE;
+  } else if (rt.ops.size() < (1u << 31)) {
+    // general scenes (planars, instances, image / noise textures): world-space tree over the primitive occurrences
+    if (!build_fast_general(*desc, rt, H->fg)) H->fg = FastGeneral{};
   }
   out = H;
   return RL_OK;
@@ -390,7 +394,8 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (rc = upload(rt.image_pool, &s->d_image_pool)) || (rc = upload(rt.perlins, &s->d_perlins)) || (rc = scene_common(s)) ||
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
-      (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes)))) {
+      (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes))) ||
+      (H->fg.ok && ((rc = upload(H->fg.nodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items))))) {
     destroy_one(s);
     return nullptr;
   }
@@ -565,6 +570,9 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   const uint32_t n_cops = (uint32_t)H.cops.size();
   P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
+  P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_root = H.fg.root, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
+  P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
+  P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;
   chacha_key_from_seed(cam->seed, P.key);
   P.first_sample = first_sample;
@@ -612,8 +620,11 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
 #ifndef RL_EXPERIMENTAL
   if (variant == 3 || variant == 5 || variant == 6 || variant == 7) return set_err(RL_E_UNSUPPORTED, "experimental kernel variants live in librl_render_exp.so only");
 #endif
+  // 1031 = the FAST traversal for general scenes (rl_rtiow_fastgen.h): counter-free renders only, like 1029
+  const bool fits_fastg = general && H.fg.ok && (!want_stats) && g_fast_traversal;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
-  else if (general || variant == 4) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
+  else if ((variant == 0 || variant == 1031) && fits_fastg) variant = 1031;
+  else if (general || variant == 4 || variant == 1031) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
   const size_t compact_bytes = ((size_t)n_cops * sizeof(CompactOp) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
   bool fits_compact = n_cops != 0 && (size_t)16 * 1024 * sizeof(unsigned long long) + compact_bytes <= g_lds_max;
   if (fits_compact) {
@@ -658,6 +669,11 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       constexpr int NT = 256;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+    } else if (variant == 1031) {  // rings + the traversal stacks in LDS (288 B per lane): 512 lanes per CU
+      constexpr int NT = 512;
+      size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + FASTG_MAX_DEPTH * sizeof(uint32_t));
+      bool trans = rt.has_noise || rt.has_sphere_uv;
+      rc = trans ? launch(rtiow_fast_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_fast_general_kernel<NT, false>, NT, rb, false);
     } else if (variant == 4) {
       // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of
       // scenes that have Noise textures or Image textures on spheres).  At 768 lanes (168 VGPRs) the spills land in the TRAV
@@ -716,7 +732,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
   const bool lpt_enabled = g_lpt;
   const uint32_t lpt_first = 8;
-  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
+  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 1031 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;
   if (variant == 3) {
@@ -808,6 +824,13 @@ void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
 void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
 void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
+#ifdef RL_FASTG_VERIFY
+int rl_debug_fastg_verify(unsigned int *count, double *log768) {
+  HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(rl::g_vcount), 4));
+  HIP_TRY(hipMemcpyFromSymbol(log768, HIP_SYMBOL(rl::g_vlog), 64 * 12 * 8));
+  return RL_OK;
+}
+#endif
 // rays of the render rl_render_status last waited for that the fast traversal re-traced in the reference's order
 unsigned long long rl_debug_slow_traces(void) { return g_last_slow_traces; }
 int rl_debug_has_experimental(void) {

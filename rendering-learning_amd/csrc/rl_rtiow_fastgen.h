@@ -1,0 +1,520 @@
+// RTIOW all-primitives kernel with the FAST traversal (counter-free renders only): the wave-scheduled state machine of
+// rl_rtiow_wave_general.h walking the world-space surface-area-heuristic tree of rl_fast_bvh.cpp (build_fast_general) instead of the
+// reference's threaded program.
+//
+//   TRAV  one 64-byte node from HBM / L2 / Infinity Cache = both children's binary32 boxes: reject-only tests (rl_rtiow_wave.h
+//         ray_aux32_direct), nearer child first, the farther one pushed on a per-lane stack in LDS ([entry][lane]: conflict-free)
+//   LEAF  one primitive OCCURRENCE: the world ray is taken through the occurrence's PUSH chain (transform.rs:145-149, translate.rs:15)
+//         and the reference's Sphere::hit / Plane::hit_ab arithmetic yields the root only — no HitRecord is kept while traversing
+//   SHADE the winning occurrence is evaluated once more with ray_t.max = its root (same arithmetic, same root) for the full
+//         HitRecord, which then takes the POP chain (transform.rs:152-161) — or, for an order-sensitive ray, the whole ray is re-traced by
+//         general_slow_trace, the reference's own fold — and is shaded as in rl_rtiow_wave_general.h
+// No XF state, no HitRecord and no second ray live across states: 2 instead of 6 wave states touch the scene.
+// Order-sensitive rays (rl_fast_bvh.cpp): two roots within fast_tie_band of each other, grazing sphere hits, planar hits within 1e-9 of an edge,
+// rays outside the binary32 filter's range or whose origin is farther than r_safe from the scene's centre, stack overflow.
+#pragma once
+#include "rl_rtiow_general.h"
+#include "rl_rtiow_wave.h"
+
+namespace rl {
+
+// The reference's fold over its own program (bvh.rs:79-95, hittable/mod.rs:88-111, transform.rs:143-164), exact divisions; returns the
+// HitRecord in world space and the number of panic sites reached.
+template <bool TRANS>
+__device__ __forceinline__ uint32_t general_slow_trace(const RtiowParams &P, const DevOp *ops, D3 wo, D3 wd, double time, Rec &rec) {
+  uint32_t flags = 0;
+  D3 o = wo, d = wd;
+  uint32_t pc = 0;
+#pragma unroll 1
+  for (;;) {
+    const DevOp &op = ops[pc];
+    uint32_t code = op.code & 0xFFu;
+    if (code == OP_END) break;
+    if (code == OP_BOX || code == OP_BOX_SPH || code == OP_BOX_PLANAR) {
+      double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+      if (!aabb_hit(bx, o, d, 1e-10, rec.t)) {
+        pc = op.skip;
+        continue;
+      }
+      if (code == OP_BOX) {
+        pc++;
+        continue;
+      }
+    }
+    if (code == OP_BOX_SPH || code == OP_SPHERE) {
+#pragma unroll 1
+      for (int k = 0; k < 2; k++) {
+        uint32_t pl = k == 0 ? op.a : op.b;
+        if (pl == NONE || (k == 1 && code == OP_SPHERE)) continue;
+        uint32_t si = pl & SPH_INDEX;
+        if (sphere_hit_rec(P.spheres[si], pl, P.sphere_material[si], pc, o, d, time, rec)) flags++;
+      }
+      pc = code == OP_SPHERE ? pc + 1 : op.skip;
+      continue;
+    }
+    if (code == OP_BOX_PLANAR || code == OP_PLANAR) {
+#pragma unroll 1
+      for (int k = 0; k < 2; k++) {
+        uint32_t pl = k == 0 ? op.a : op.b;
+        if (pl == NONE || (k == 1 && code == OP_PLANAR)) continue;
+        if (planar_hit_rec(P.planars[pl], pc, o, d, rec)) flags++;
+      }
+      pc = code == OP_PLANAR ? pc + 1 : op.skip;
+      continue;
+    }
+    if (code == OP_PUSH_TRANSLATE) o = o - ld3(P.translates[op.a].offset);
+    else if (code == OP_PUSH_TRANSFORM) {
+      const rl_transform &t = P.transforms[op.a];
+      D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
+      o = no, d = nd;
+    } else {  // POP: op.b = the matching PUSH, whose .b is the parent PUSH
+      uint32_t push_pc = op.b;
+      if (rec.any && rec.pc > push_pc) {
+        if (code == OP_POP_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);
+        else {
+          const rl_transform &t = P.transforms[op.a];
+          rec.p = mat3_mul(t.m, rec.p);
+          D3 wn = mat3_mul(t.inv_t, rec.normal);
+          double m = len2(wn);
+          if (approx_eq_eps(m, 0.0, 1e-16)) flags++;
+          else rec.normal = normalize(wn);
+        }
+      }
+      replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
+    }
+    pc++;
+  }
+  return flags;
+}
+
+#ifdef RL_FASTG_VERIFY  // debug build (tools/verify_fastg.py): every ray is ALSO traced in the reference's order; mismatches are logged
+__device__ unsigned int g_vcount;
+__device__ double g_vlog[64][12];
+#endif
+// Sphere::hit / Plane::hit_ab for the ROOT only, acceptance window widened by the tie band (see fast_sphere_hit in rl_rtiow_wave.h)
+__device__ __forceinline__ void fastg_planar_hit(const DevPlanar &pl, D3 o, D3 d, float oimax, uint32_t item, double &closest, uint32_t &best, bool &amb) {
+  D3 normal = ld3(pl.normal);
+  double denom = dot(normal, d);
+  if (fabs(denom) < 1e-8) return;
+  double t = (pl.d - dot(normal, o)) / denom;
+  // t's rounding error scales with the cancelling terms of its numerator, not with t
+  const double band = fast_tie_band((fabs(pl.d) + fabs(normal.x * o.x) + fabs(normal.y * o.y) + fabs(normal.z * o.z)) / fabs(denom), oimax);
+  if (!(1e-10 <= t && t <= closest + band)) return;
+  D3 p = o + d * t;
+  D3 hp = p - ld3(pl.q);
+  D3 w = ld3(pl.w);
+  double alpha = dot(w, cross(hp, ld3(pl.v)));
+  double beta = dot(w, cross(ld3(pl.u), hp));
+  // within the hit point's own uncertainty (root error x |d|, seen through alpha = w . (hp x v), beta = w . (u x hp)) of an edge: the
+  // reference's leaf box is the exact bound of the vertices, so such a hit may or may not pass it
+  const double w1 = fabs(w.x) + fabs(w.y) + fabs(w.z), d1 = fabs(d.x) + fabs(d.y) + fabs(d.z);
+  const double uv1 = fmax(fabs(pl.u[0]) + fabs(pl.u[1]) + fabs(pl.u[2]), fabs(pl.v[0]) + fabs(pl.v[1]) + fabs(pl.v[2]));
+  const double e = 1e-9 + band * d1 * w1 * uv1;
+  bool inside, edge;
+  if (pl.kind == RL_PLANAR_QUAD) {
+    inside = 0.0 <= alpha && alpha <= 1.0 && 0.0 <= beta && beta <= 1.0;
+    edge = fabs(alpha) <= e || fabs(alpha - 1.0) <= e || fabs(beta) <= e || fabs(beta - 1.0) <= e;
+  } else {  // triangle (build_fast_general admits no unbounded Plane)
+    inside = 0.0 <= alpha && 0.0 <= beta && alpha + beta <= 1.0;
+    edge = fabs(alpha) <= e || fabs(beta) <= e || fabs(alpha + beta - 1.0) <= e;
+  }
+  if (!inside) return;
+  if (edge) amb = true;  // an edge-grazing hit may or may not pass the reference's own leaf box (the exact bound of the vertices)
+  if (best != NONE && fabs(t - closest) <= band) amb = true;
+  if (t <= closest) closest = t, best = item;
+}
+
+__device__ __forceinline__ void fastg_sphere_hit(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time, float oimax, uint32_t item, double &closest,
+                                                 uint32_t &best, bool &amb) {
+  D3 c0 = ld3(s.c0);
+  D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+  D3 oc = o - center;
+  double a = len2(d);
+  double half_b = dot(oc, d);
+  double c = len2(oc) - s.r2;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return;
+  double sq = sqrt(disc);
+  double r_l = (-half_b - sq) / a;
+  double r_u = (-half_b + sq) / a;
+  // a sphere seen from more than ~5e4 radii away: the reference's from_normalized assert (vec3.rs:219) can fire for it, and whether
+  // it is accepted along the way depends on the reference's order (rays from inside r_safe never get here: build_fast_general)
+  if ((r_l >= 1e-10 || r_u >= 1e-10) && c + s.r2 > 2.5e9 * s.r2) amb = true;
+  const double band = fast_tie_band(fabs(r_l) + fabs(r_u), oimax);
+  const double hi = closest + band;
+  double t;
+  if (1e-10 <= r_l && r_l <= hi) t = r_l;
+  else if (1e-10 <= r_u && r_u <= hi) t = r_u;
+  else return;
+  if (best != NONE && fabs(t - closest) <= band) amb = true;  // grazing / pole hits: only the winner matters, checked in SHADE
+  if (t <= closest) closest = t, best = item;
+}
+
+template <int NT, bool TRANS>
+__global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  unsigned long long *s_rng = (unsigned long long *)smem;                                   // [16][NT]
+  uint32_t *s_stack = (uint32_t *)(smem + (size_t)16 * NT * sizeof(unsigned long long));  // [FASTG_MAX_DEPTH][NT]
+  const DevOp *ops = P.ops;
+  const FastNodeG *nodes = P.fg_nodes;
+  const FastItem *items = P.fg_items;
+  const rl_rtiow_camera &cam = P.cam;
+  const uint32_t W = cam.image_width;
+  const uint32_t s_begin = P.sample_begin, spp = P.sample_end;
+  const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  const float FINF = __int_as_float(0x7F800000);
+
+  Ring<NT> rng{P.key, s_rng, tid, 0ull, 0u, 0u, 0u};
+  uint32_t state = ST_GEN;
+  uint32_t px = 0, pr = 0, n = spp;
+  uint32_t ptile = 0, pix_rays = 0;
+  bool have_pixel = false;
+  D3 sum = d3(0.0, 0.0, 0.0);
+  D3 wo = d3(0.0, 0.0, 0.0), wd = d3(0.0, 0.0, 1.0);
+  D3 thr = d3(1.0, 1.0, 1.0);
+  RayAux32 ra32 = ray_aux32_direct(wo, wd);
+  double time = 0.0, closest = INF;
+  uint32_t pc = 0, best = NONE, depth = 0, sp = 0;
+  bool amb = false;
+  // rays that start farther than r_safe from the scene's centre (e.g. inside a huge ground sphere): the boxes' padding was sized for
+  // origins inside r_safe, so such a ray widens every box interval by `grow` and does NOT prune by the closest hit — every sphere its
+  // line touches is then tested, and fastg_sphere_hit's far-origin check covers everything the reference could accept on the way
+  float grow = 0.0f;
+  bool unsafe = false;
+  uint32_t c_rays = 0, c_flag = 0, c_slow = 0;
+
+  auto go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), an item (LEAF), or nothing left (SHADE)
+    if (e == NONE) {
+#ifdef RL_FASTG_VERIFY
+      if (false) {
+#else
+      if (!amb && best == NONE) {  // a miss needs no SHADE visit: background (camera.rs:257), sample done
+#endif
+        sum = sum + thr * ld3(cam.background);
+        n++;
+        state = ST_GEN;
+      } else state = ST_SHADE;
+    } else {
+      pc = e;
+      state = (e & FASTG_LEAF) ? ST_LEAF : ST_TRAV;
+    }
+  };
+  auto pop = [&]() -> uint32_t {
+    if (sp == 0) return NONE;
+    sp--;
+    return s_stack[(size_t)sp * NT + tid];
+  };
+  auto start_ray = [&]() {
+    closest = INF, best = NONE, sp = 0;
+    ra32 = ray_aux32_direct(wo, wd);
+    float fx = (float)wo.x - P.fg_center[0], fy = (float)wo.y - P.fg_center[1], fz = (float)wo.z - P.fg_center[2];
+    float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
+    amb = !(ra32.slack < FINF);  // outside the binary32 filter's range: the reference's order
+    unsafe = !(far2 <= P.fg_rsafe2);
+    grow = 0.0f;
+    if (unsafe) {  // pad(L) = fg_pad_k * L^2 in world units (rl_fast_bvh.cpp), L = distance to the centre + the scene's radius; in units of t: / min |d_k|
+      float L = sqrtf(far2) + P.fg_radius;
+      grow = P.fg_pad_k * L * L * fmaxf(fmaxf(fabsf(ra32.invx), fabsf(ra32.invy)), fabsf(ra32.invz));
+      if (!(grow < FINF)) amb = true;
+    }
+    go(amb ? NONE : P.fg_root);
+  };
+
+  for (;;) {
+    if (state == ST_SHADE && rng.low()) state = ST_FILL;
+    int n_trav = __popcll(__ballot(state == ST_TRAV));
+    int n_shade = __popcll(__ballot(state == ST_SHADE));
+    int n_fill = __popcll(__ballot(state == ST_FILL));
+    int n_gen = __popcll(__ballot(state == ST_GEN));
+    int n_leaf = __popcll(__ballot(state == ST_LEAF));
+    if ((n_trav | n_shade | n_fill | n_gen | n_leaf) == 0) break;
+    uint32_t pick = ST_TRAV;
+    int bestn = n_trav;
+    if (n_leaf > bestn) pick = ST_LEAF, bestn = n_leaf;
+    if (n_shade > bestn) pick = ST_SHADE, bestn = n_shade;
+    if (n_fill > bestn) pick = ST_FILL, bestn = n_fill;
+    if (n_gen > bestn) pick = ST_GEN, bestn = n_gen;
+
+    if (pick == ST_TRAV) {
+      int floor_n = (bestn * (int)P.tune[1]) >> 4;
+      for (int it = 0; it < (int)P.tune[0]; it++) {
+        if (state == ST_TRAV) {
+          const Float4 *nd = (const Float4 *)(nodes + pc);
+          const Float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
+          const uint2 ch = *(const uint2 *)((const unsigned char *)(nodes + pc) + 48);
+          const float c32 = unsafe ? FINF : (float)closest;
+          auto missed = [&](float b0, float b1, float b2, float b3, float b4, float b5, float &tmin) {
+            float t0x = fmaf(b0, ra32.invx, -ra32.oix), t1x = fmaf(b1, ra32.invx, -ra32.oix);
+            float t0y = fmaf(b2, ra32.invy, -ra32.oiy), t1y = fmaf(b3, ra32.invy, -ra32.oiy);
+            float t0z = fmaf(b4, ra32.invz, -ra32.oiz), t1z = fmaf(b5, ra32.invz, -ra32.oiz);
+            tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)) - grow, 1e-10f);
+            float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) + grow, c32);
+            float diff = tmax - tmin;
+            float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
+            return diff < -thresh;
+          };
+          float tA, tB;
+          const bool hitA = !missed(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tA);
+          const bool hitB = !missed(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tB);
+          const bool a_first = hitA && (!hitB || tA <= tB);
+          uint32_t first = a_first ? ch.x : ch.y;
+          if (hitA && hitB) {
+            if (sp < FASTG_MAX_DEPTH) s_stack[(size_t)sp * NT + tid] = a_first ? ch.y : ch.x, sp++;
+            else amb = true;  // cannot happen for a tree build_fast_general made (depth <= FASTG_MAX_DEPTH)
+          }
+          if (!(hitA || hitB)) first = pop();
+          go(first);
+        }
+        if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
+      }
+    } else if (pick == ST_LEAF) {
+      if (state == ST_LEAF) {
+        const uint32_t item = pc & ~FASTG_LEAF;
+        const FastItem it = items[item];
+        D3 o, d;
+        replay_chain(P, ops, it.chain, wo, wd, o, d);
+        // the tie band's coordinate scale max |o_k / d_k| of the ray the test actually sees (binary32 is plenty for a tolerance)
+        float oimax = ra32.oimax();
+        if (it.chain != NONE)
+          oimax = fmaxf(fmaxf(fabsf((float)o.x * __builtin_amdgcn_rcpf((float)d.x)), fabsf((float)o.y * __builtin_amdgcn_rcpf((float)d.y))),
+                        fabsf((float)o.z * __builtin_amdgcn_rcpf((float)d.z)));
+        if (!(oimax < FINF)) oimax = FINF;  // NaN (0 * inf) -> every hit of this item counts as a tie
+        if (it.kind == 0) fastg_sphere_hit(P.spheres[it.payload & SPH_INDEX], it.payload, o, d, time, oimax, item, closest, best, amb);
+        else fastg_planar_hit(P.planars[it.payload], o, d, oimax, item, closest, best, amb);
+        go(pop());
+      }
+    } else if (pick == ST_FILL) {
+      if (state == ST_FILL) {
+        rng.top_up();
+        state = ST_SHADE;
+      }
+    } else if (pick == ST_GEN) {
+      if (state == ST_GEN) {
+        bool active = true;
+        if (n >= spp) {
+          if (have_pixel) {
+            size_t pix = (size_t)pr * W + px;
+            double *outp = P.out + pix * 3;
+            outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+            if (P.pos_state) P.pos_state[pix] = rng.pos;
+            if (P.tile_cost) atomicAdd(&P.tile_cost[ptile], pix_rays);
+            have_pixel = false;
+          }
+          uint32_t slot = wave_claim(P.work_counter);
+          if (slot >= P.n_slots) {
+            state = ST_DONE;
+            active = false;
+          } else {
+            uint32_t tile = slot >> 6, in = slot & 63u;
+            if (P.tile_order) tile = P.tile_order[tile];
+            ptile = tile;
+            px = (tile % P.tiles_x) * 8u + (in & 7u);
+            pr = (tile / P.tiles_x) * 8u + (in >> 3);
+            if (px >= W || pr >= P.nrows) active = false;
+            else {
+              have_pixel = true;
+              n = s_begin;
+              pix_rays = 0;
+              if (P.resume) {
+                size_t pix = (size_t)pr * W + px;
+                const double *inp = P.out + pix * 3;
+                sum = d3(inp[0], inp[1], inp[2]);
+                rng.pos = P.pos_state[pix];
+              } else {
+                rng.pos = 0;
+                sum = d3(0.0, 0.0, 0.0);
+              }
+              rng.nres = 0;
+              if (n >= spp) active = false;
+            }
+          }
+        }
+        if (active) {
+          uint32_t y = P.row_first + pr * P.row_step;
+          uint64_t sample_index = (uint64_t)n + P.first_sample;
+          rng.reset_stream(sample_index * WH + (uint64_t)px * (uint64_t)W + (uint64_t)y);
+          D3 p00 = ld3(cam.pixel_00), du = ld3(cam.pixel_du), dv = ld3(cam.pixel_dv);
+          D3 pixel_center = (p00 + du * (double)px) + dv * (double)y;
+          double sx = -0.5 + rng.gen_f64();
+          double sy = -0.5 + rng.gen_f64();
+          D3 pixel_sample = pixel_center + (du * sx + dv * sy);
+          if (cam.defocus_angle <= 0.0) wo = ld3(cam.lookfrom);
+          else {
+            double a, b;
+            rng.unit_disc(a, b);
+            wo = (ld3(cam.lookfrom) + ld3(cam.defocus_disk_u) * a) + ld3(cam.defocus_disk_v) * b;
+          }
+          wd = pixel_sample - wo;
+          time = rng.gen_f64();
+          thr = d3(1.0, 1.0, 1.0);
+          depth = cam.max_depth;
+          if (depth == 0) n++;
+          else {
+            c_rays++;
+            pix_rays++;
+            start_ray();
+          }
+        }
+      }
+    } else {  // ST_SHADE
+      if (state == ST_SHADE) {
+        bool path_done = false;
+        D3 nd = wd;
+        Rec rec;
+        rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false, rec.front = true;
+        rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
+        if (amb) {  // rare: the answer may depend on the visiting order -> the reference's own fold
+          c_flag += general_slow_trace<TRANS>(P, ops, wo, wd, time, rec);
+          c_slow++;
+        } else if (best != NONE) {
+          bool push_skip = false;
+          // the HitRecord of the winner: the same test once more with ray_t.max = its root (same arithmetic -> same root), then the
+          // POP chain innermost first, as the reference's recursion unwinds (transform.rs:152-161, translate.rs:18)
+          const FastItem it = items[best];
+          D3 o, d;
+          replay_chain(P, ops, it.chain, wo, wd, o, d);
+          rec.t = closest;
+          bool sensitive = false;
+          if (it.kind == 0) {
+            uint32_t si = it.payload & SPH_INDEX;
+            const DevSphere &sp = P.spheres[si];
+            sphere_hit_rec(sp, it.payload, P.sphere_material[si], it.op_pc, o, d, time, rec);  // its flag: unreachable (r_safe)
+            D3 c0 = ld3(sp.c0);
+            D3 center = (it.payload & SPH_MOVING) ? c0 + ld3(sp.dc) * time : c0;
+            float oimax = ra32.oimax();
+            if (it.chain != NONE)
+              oimax = fmaxf(fmaxf(fabsf((float)o.x * __builtin_amdgcn_rcpf((float)d.x)), fabsf((float)o.y * __builtin_amdgcn_rcpf((float)d.y))),
+                            fabsf((float)o.z * __builtin_amdgcn_rcpf((float)d.z)));
+            if (!(oimax < FINF)) oimax = FINF;
+            {  // the winner only: a sphere the reference prunes changes the reference's answer only if it would have won
+              D3 oc = o - center;
+              double half_b = dot(oc, d), sq = sp.r2 * sp.inv_r * fabs(dot(d, rec.normal)), a = len2(d);
+              double other = 2.0 * sq * (double)__builtin_amdgcn_rcpf((float)a);  // the other root is t -+ 2 sqrt(disc) / a
+              sensitive = fast_hit_is_order_sensitive(oc, d, closest, sp.r2 * sp.inv_r, half_b, sq, closest, fabs(closest) + other, oimax);
+            }
+          } else planar_hit_rec(P.planars[it.payload], it.op_pc, o, d, rec);
+          if (sensitive) {  // rare: grazing or next to an axis pole -> the reference's own fold decides
+            rec.t = INF, rec.any = false;
+            c_flag += general_slow_trace<TRANS>(P, ops, wo, wd, time, rec);
+            c_slow++;
+            push_skip = true;
+          }
+          uint32_t push_pc = push_skip ? NONE : it.chain;  // (the slow trace returns a world-space record)
+#pragma unroll 1
+          while (push_pc != NONE) {
+            const DevOp &op = ops[push_pc];
+            if ((op.code & 0xFFu) == OP_PUSH_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);
+            else {
+              const rl_transform &t = P.transforms[op.a];
+              rec.p = mat3_mul(t.m, rec.p);
+              D3 wn = mat3_mul(t.inv_t, rec.normal);
+              double m = len2(wn);
+              if (approx_eq_eps(m, 0.0, 1e-16)) c_flag++;  // unreachable: build_fast_general bounds the matrices
+              else rec.normal = normalize(wn);
+            }
+            push_pc = op.b;
+          }
+        }
+#ifdef RL_FASTG_VERIFY
+        {
+          Rec r2;
+          r2.t = INF, r2.any = false, r2.pc = 0, r2.mat = 0, r2.u = 0.0, r2.v = 0.0, r2.w = 0.0, r2.uv3 = false, r2.front = true;
+          r2.p = d3(0.0, 0.0, 0.0), r2.normal = d3(0.0, 0.0, 0.0);
+          general_slow_trace<TRANS>(P, ops, wo, wd, time, r2);
+          bool same = rec.any == r2.any && (!rec.any || (rec.t == r2.t && rec.pc == r2.pc && rec.p.x == r2.p.x && rec.normal.y == r2.normal.y));
+          if (!same) {
+            unsigned k = atomicAdd(&g_vcount, 1u);
+            if (k < 64) {
+              double *L = g_vlog[k];
+              L[0] = wo.x, L[1] = wo.y, L[2] = wo.z, L[3] = wd.x, L[4] = wd.y, L[5] = wd.z, L[6] = time, L[7] = rec.any ? rec.t : -1.0;
+              L[8] = (double)rec.pc, L[9] = r2.any ? r2.t : -1.0, L[10] = (double)r2.pc, L[11] = unsafe ? 1.0 : 0.0;
+            }
+          }
+        }
+#endif
+        D3 p = rec.p;
+        if (!rec.any) {
+          sum = sum + thr * ld3(cam.background);
+          path_done = true;
+        } else {
+          const DevMaterial &m = P.materials[rec.mat];
+          D3 texc = d3(0.0, 0.0, 0.0);
+          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+            double tu, tv;
+            rec_uv<TRANS>(rec, tu, tv);
+            texc = texture_value<(TRANS ? 2 : 1)>(P, m.texture, tu, tv, rec.p);
+          }
+          uint32_t kind = m.kind;
+          D3 normal = rec.normal;
+          if (kind == RL_MAT_LAMBERTIAN) {
+            D3 dir = normal + rng.unit_sphere();
+            bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
+            nd = near_zero ? normal : dir;
+            thr = thr * texc;
+          } else if (kind == RL_MAT_METAL) {
+            D3 reflected = wd - normal * (2.0 * dot(wd, normal));
+            nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
+            if (!(dot(nd, normal) > 0.0)) path_done = true;
+            else thr = thr * ld3(m.albedo);
+          } else if (kind == RL_MAT_DIELECTRIC) {
+            double ri = rec.front ? 1.0 / m.ior : m.ior;
+            double m2 = len2(wd);
+            D3 ud;
+            if (approx_eq_eps(m2, 0.0, 1e-16)) {
+              c_flag++;
+              ud = wd;
+            } else
+              ud = normalize(wd);
+            double cos_theta = fmin(dot(-ud, normal), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool reflect = ri * sin_theta > 1.0;
+            if (!reflect) {
+              double q = (1.0 - ri) / (1.0 + ri);
+              double r0 = q * q;
+              double xx = 1.0 - cos_theta;
+              double x2 = xx * xx;
+              double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
+              reflect = refl > rng.gen_f64();
+            }
+            if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
+            else {
+              D3 perp = (ud + normal * cos_theta) * ri;
+              D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
+              nd = perp + par;
+            }
+          } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
+            sum = sum + thr * texc;
+            path_done = true;
+          } else {
+            path_done = true;
+          }
+        }
+        if (!path_done) {
+          depth--;
+          if (depth == 0) path_done = true;
+        }
+        if (path_done) {
+          n++;
+          state = ST_GEN;
+        } else {
+          c_rays++;
+          pix_rays++;
+          wo = p, wd = nd;
+          start_ray();
+        }
+      }
+    }
+  }
+
+  unsigned long long v;
+  v = wave_sum((unsigned long long)c_rays);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[0], v);
+  v = wave_sum((unsigned long long)c_flag);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[6], v);
+  v = wave_sum((unsigned long long)c_slow);
+  if ((tid & 63) == 0 && v) atomicAdd(&P.stats[7], v);
+}
+
+}  // namespace rl

@@ -141,6 +141,8 @@ __device__ __forceinline__ bool aabb_fast(const double *b, const RayAux &ra, dou
 // lane evaluates the reference's divisions in binary64.  About 1 test in 10^5 falls back.
 struct RayAux32 {
   float invx, invy, invz, oix, oiy, oiz, slack;
+  // ray_aux32_direct only: max_k |o_k / d_k|, the coordinate scale of this ray in units of t (slack = 24u * that; +inf stays +inf)
+  __device__ __forceinline__ float oimax() const { return slack * 699050.6875f; }
 };
 __device__ __forceinline__ RayAux32 ray_aux32(const RayAux &a) {
   RayAux32 r;
@@ -187,6 +189,11 @@ __device__ __forceinline__ RayAux32 ray_aux32_direct(D3 o, D3 d) {
   r.slack = ok ? m * 1.430511474609375e-06f : __int_as_float(0x7F800000);  // 24u, or +inf: never certain
   return r;
 }
+// Two accepted roots closer than this are treated as a tie (the ray is re-traced in the reference's order).  The reference's own
+// decisions that involve two different primitives — `tmin < closest` on its boxes, `t <= closest` in Sphere::hit — compare values
+// whose rounding errors are a few u (2^-53) times the SCALES involved: the far root of the sphere (cancellation in -half_b -+ sqrt),
+// and the coordinates of origin and boxes over the direction (max |o/d|).  4e-12 is ~4e4 u.
+__device__ __forceinline__ double fast_tie_band(double scale_t, float oimax) { return 4e-12 * (scale_t + (double)oimax); }
 
 // LDS_SCENE: 0 = scene read from HBM / L2, 1 = linked ops + spheres staged in LDS, 2 = linked ops in LDS, spheres from L2,
 // 3 = compact (32-byte) guarded ops in LDS (P.cops: the n_ops originals + one guard op per sphere), spheres from L2,
@@ -203,16 +210,54 @@ typedef __attribute__((address_space(3))) const uint32_t LdsU32;
 // [1e-10, closest]), descends into the nearer child and pushes the farther one on a 16-entry stack held in five VGPRs (ten-bit entry
 // ids, v_alignbit shifts) — ~12 steps and ~1.9 Sphere::hit per ray.  Whenever the visiting ORDER could influence the reference's answer
 // the ray is flagged and re-traced by fast_slow_trace, the reference's own fold with exact divisions:
-//   * two roots within 1e-7 relative of each other (exact ties go to the LAST sphere in the reference's order; `tmin < closest`
-//     pruning on the reference's boxes),
-//   * a grazing hit (chord below 1e-6 relative: the reference's unpadded leaf box may or may not be passed),
+//   * two roots within a few 1e4 ulps of the scales involved (fast_tie_band; exact ties go to the LAST sphere in the reference's
+//     order; `tmin < closest` pruning on the reference's boxes),
+//   * a grazing hit (chord below 1e-6 relative: the reference's unpadded leaf box may or may not be passed), or a hit next to one
+//     of the sphere's axis poles, where it touches its own box (fast_near_box_face),
 //   * (a hit whose outward normal trips the from_normalized assert, vec3.rs:219, would make the panic-site count order dependent:
 //     scenes in which that assert is reachable do not get a fast structure at all, rl_fast_bvh.cpp normals_safe),
 //   * a ray outside the filter's range (zero / denormal-scale / huge direction component, far-away origin).
 static const uint32_t FAST_SLOW = 0xFFFFFFFFu;  // pc of a lane in ST_LEAF that must re-trace its ray in the reference's order
 
+// A sphere touches its own bounding box (and every ancestor box it is extremal in) at its six axis poles.  The ROUNDED root can sit a
+// little past the point where the ray leaves that box — e.g. the self-intersection root ~1e-10 of a ray that starts on top of a huge
+// ground sphere, whose cancellation error is as large as the root itself — and then the reference's exact slab test (aabb.rs:123-152)
+// prunes a sphere that Sphere::hit would have accepted.  The hit is order-sensitive when its point is closer to a face of
+// [centre - r, centre + r] than the root's error bound moves it along the ray.
+// Bound on the error of Sphere::hit's rounded roots, in units of t: the discriminant carries ~16u a |oc|^2 of rounding (cancellation in
+// |oc|^2 - r^2 and half_b^2 - a c), i.e. 8u |oc|^2 / sqrt(disc) in the root, plus a few u of the roots' magnitudes and of the coordinate
+// scale max |o/d|; times 64.  (The tie band above is far wider; this one decides how close to a box face a hit may lie.)
+__device__ __forceinline__ double fast_root_error(double len2_oc, double sq, double r_l, double r_u, float oimax) {
+  float q = (float)len2_oc * __builtin_amdgcn_rcpf((float)sq);  // a tolerance: binary32 is plenty; sq = 0 -> +inf
+  return 64.0 * (1.8e-15 * (double)q + 4.5e-16 * (fabs(r_l) + fabs(r_u) + (double)oimax));
+}
+__device__ __forceinline__ bool fast_near_box_face(D3 o, D3 d, double t, D3 center, double r, double band) {
+  D3 q = (o + d * t) - center;
+  return r - fabs(q.x) <= band * fabs(d.x) || r - fabs(q.y) <= band * fabs(d.y) || r - fabs(q.z) <= band * fabs(d.z);
+}
+
+// Grazing hits and hits next to an axis pole, for an ACCEPTED root t (rl_rtiow_fastgen.h: for the winning hit).  A binary32 pre-filter
+// on what Sphere::hit has already computed lets all but ~3 hits in 10^4 skip the exact test: |q_k| < 0.9999 r for q = oc + t d (not
+// within 1e-4 r of a face), sqrt(disc) > 1e-3 |d|_max r (not grazing), and the root's error bound below half of that 1e-4 r.
+__device__ __forceinline__ bool fast_hit_is_order_sensitive(D3 oc, D3 d, double t, double r, double half_b, double sq, double r_l, double r_u, float oimax) {
+  float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z, t32 = (float)t, r32 = (float)r, sq32 = (float)sq;
+  float ox = (float)oc.x, oy = (float)oc.y, oz = (float)oc.z;
+  float qm = fmaxf(fmaxf(fabsf(fmaf(dx, t32, ox)), fabsf(fmaf(dy, t32, oy))), fabsf(fmaf(dz, t32, oz)));
+  float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+  float l2 = fmaf(ox, ox, fmaf(oy, oy, oz * oz));
+  // eps |d_k| <= 64 * 1.8e-15 |oc|^2 / sqrt(disc) * max |d_k| (+ lower-order terms) must stay below 5e-5 r
+  bool quiet = 2.4e-13f * l2 * dmax < 5e-5f * r32 * sq32 && qm < 0.9999f * r32 && sq32 > 1e-3f * dmax * r32;
+  if (quiet) return false;
+  D3 q = oc + d * t;
+  double eps = fast_root_error(len2(oc), sq, r_l, r_u, oimax);
+  bool grazing = sq <= 1e-6 * fabs(half_b);
+  bool pole = r - fabs(q.x) <= eps * fabs(d.x) || r - fabs(q.y) <= eps * fabs(d.y) || r - fabs(q.z) <= eps * fabs(d.z);
+  return grazing || pole || !(eps * (double)dmax < 5e-5 * r);
+}
+
 // Sphere::hit (sphere.rs:32-75) with the acceptance window widened by the tie band; same arithmetic, same root values.
-__device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time, double &closest, uint32_t &hit_prim, bool &amb) {
+__device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time, float oimax, double &closest, uint32_t &hit_prim,
+                                                bool &amb) {
   D3 c0 = ld3(s.c0);
   D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
   D3 oc = o - center;
@@ -224,16 +269,14 @@ __device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t pay
   double sq = sqrt(disc);
   double r_l = (-half_b - sq) / a;
   double r_u = (-half_b + sq) / a;
-  const double band = 1e-7 * (fabs(r_l) + fabs(r_u));
+  const double band = fast_tie_band(fabs(r_l) + fabs(r_u), oimax);
   const double hi = closest + band;  // +inf stays +inf
   double t;
   if (1e-10 <= r_l && r_l <= hi) t = r_l;
   else if (1e-10 <= r_u && r_u <= hi) t = r_u;
   else return;
   // no from_normalized check here: build_fast_bvh only accepts scenes whose frame makes that assert unreachable (GuardFrame::normals_safe)
-  bool near_tie = hit_prim != NONE && fabs(t - closest) <= band;
-  bool grazing = sq <= 1e-6 * fabs(half_b);
-  amb = amb || near_tie || grazing;
+  amb = amb || (hit_prim != NONE && fabs(t - closest) <= band) || fast_hit_is_order_sensitive(oc, d, t, s.r2 * s.inv_r, half_b, sq, r_l, r_u, oimax);
   if (t <= closest) closest = t, hit_prim = payload;
 }
 
@@ -620,7 +663,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             const uint32_t sidx = pc - P.n_fast_inner;
             const uint32_t payload = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u);
             if (STATS) c_sph++;
-            fast_sphere_hit(spheres[sidx], payload, o, d, time, closest, hit_prim, amb);
+            fast_sphere_hit(spheres[sidx], payload, o, d, time, ra32.oimax(), closest, hit_prim, amb);
             fast_go(fast_pop());
           }
         }

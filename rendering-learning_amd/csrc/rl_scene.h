@@ -28,6 +28,7 @@ struct HostRtiow {
   uint32_t entry0 = 0, centry0 = 0;
   std::vector<FastNode> fast_nodes;  // fast traversal structure (rl_fast_bvh.cpp); fast_root == FAST_NONE: the scene does not qualify
   uint32_t fast_root = FAST_NONE;
+  FastGeneral fg;  // fast traversal structure of a general scene (fg.ok == false: the scene does not qualify)
   // the guard boxes' padding is rigorous for ray origins within guard_reach of guard_center (rl_render.hip link_ops)
   double guard_center[3] = {0, 0, 0}, guard_reach = 0;
 };
@@ -53,6 +54,8 @@ struct rl_scene {
   rl::CompactOp *d_cops = nullptr;
   uint32_t *d_movbits = nullptr;
   rl::FastNode *d_fast_nodes = nullptr;
+  rl::FastNodeG *d_fg_nodes = nullptr;
+  rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
   rl::DevPlanar *d_planars = nullptr;

@@ -184,3 +184,88 @@ def test_grazing_rays_over_a_sphere_horizon(rl, oracle):
     p = rl.CameraParams(aspect_ratio=4.0, image_width=256, samples_per_pixel=8, max_depth=10, vfov=3.0, lookfrom=(0, 0.02, 10), lookat=(0, -0.45, -90),
                         background=(0.6, 0.7, 0.9), seed=5)
     _check(rl, oracle, world, p)
+
+
+# ------------------------------------------------------------------------------------------------ general scenes (rl_rtiow_fastgen.h)
+def _spot_texture():
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.abspath(__file__))
+    return np.asarray(Image.open(os.path.join(root, "golden", "spot_texture.png")).convert("RGB"))
+
+
+def _general_scenes(rl, golden):
+    tex = _spot_texture()
+    lin = (tex.astype(np.float32) / 255.0) ** 2.2
+
+    def composed(b):  # every primitive kind, an instance chain of scale -> rotate_x -> rotate_z -> translate around a BVH
+        red = b.lambertian(b.solid((0.8, 0.2, 0.2)))
+        chk = b.lambertian(b.checker(0.5, b.solid((0.1, 0.1, 0.1)), b.solid((0.9, 0.9, 0.9))))
+        mirror = b.metal((0.8, 0.8, 0.8), 0.05)
+        glass = b.dielectric(1.5)
+        light = b.diffuse_light(b.solid((4.0, 4.0, 4.0)))
+        objs = [b.sphere((0, 0, -1), 0.5, red), b.sphere((1.2, 0, -1.5), 0.5, glass), b.sphere((-1.2, 0.1, -1.2), 0.4, mirror, center2=(-1.2, 0.4, -1.2)),
+                b.quad((-3, -0.5, -4), (6, 0, 0), (0, 0, 5), chk), b.triangle((-1, 0.8, -2), (2, 0, 0), (0, 1.5, 0), light)]
+        tri = b.triangle_from_model([[0, 0, 0], [1, 0, 0], [0, 1, 0]], red, uvs=[[0, 0], [1, 0], [0, 1]], normals=[[0, 0, 1], [0.2, 0, 1], [0, 0.2, 1]])
+        inner = b.bvh([b.sphere((0, 0, 0), 0.3, red), tri, b.quad((0, 0, 0.2), (0.5, 0, 0), (0, 0.5, 0), glass)])
+        inst = b.translate(b.rotate_z(b.rotate_x(b.scale(inner, 1.5), 25.0), -40.0), (0.3, 0.9, -1.8))
+        return b.bvh(objs + [inst])
+
+    def cornell(b):
+        white = b.lambertian(b.solid((0.73, 0.73, 0.73)))
+        green = b.lambertian(b.solid((0.12, 0.45, 0.15)))
+        img = b.lambertian(b.image(lin[::32, ::32].copy()))
+        light = b.diffuse_light(b.solid((15, 15, 15)))
+        qs = [b.quad((555, 0, 0), (0, 555, 0), (0, 0, 555), green), b.quad((0, 0, 0), (0, 555, 0), (0, 0, 555), img),
+              b.quad((343, 554, 332), (-130, 0, 0), (0, 0, -105), light), b.quad((0, 0, 0), (555, 0, 0), (0, 0, 555), white),
+              b.quad((555, 555, 555), (-555, 0, 0), (0, 0, -555), white), b.quad((0, 0, 555), (555, 0, 0), (0, 555, 0), white),
+              b.translate(b.rotate_y(b.sphere((0, 0, 0), 90.0, b.dielectric(1.5)), 15.0), (190, 90, 190)),
+              b.quad((130, 0, 65), (165, 0, 0), (0, 165, 0), white), b.quad((130, 0, 65), (165, 0, 0), (0, 165, 0), green)]  # two coincident quads
+        return b.list(qs)
+
+    def instanced_twice(b):  # one mesh placed twice: two occurrences of every triangle
+        mat = b.lambertian(b.solid((0.6, 0.6, 0.7)))
+        mesh = b.bvh([b.triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), mat), b.triangle((1, 0, 0), (0, 1, 0), (0, 0, 1), mat),
+                      b.quad((0, 0, 0), (0, 0, 1), (0, 1, 0), mat), b.sphere((0.4, 0.4, 0.4), 0.25, b.metal((0.9, 0.8, 0.7), 0.0))])
+        return b.bvh([b.translate(mesh, (-1.2, 0, -3)), b.translate(b.rotate_y(mesh, 70.0), (0.6, -0.2, -3.5)),
+                      b.sphere((0, -100.5, -3), 100, b.lambertian(b.checker(0.7, b.solid((0.2, 0.3, 0.1)), b.solid((0.9, 0.9, 0.9))))),
+                      b.quad((-2, 1.8, -5), (4, 0, 0), (0, 0, 3), b.diffuse_light(b.solid((3, 3, 3))))])
+
+    cam1 = rl.CameraParams(aspect_ratio=1.5, image_width=120, samples_per_pixel=6, max_depth=12, vfov=60.0, lookfrom=(0.2, 0.6, 2.5), lookat=(0.0, 0.2, -1.0),
+                           defocus_angle=0.5, focus_dist=3.0, background=(0.3, 0.4, 0.6), seed=3)
+    cam2 = rl.CameraParams(aspect_ratio=1.0, image_width=64, samples_per_pixel=8, max_depth=20, vfov=40.0, lookfrom=(278, 278, -800), lookat=(278, 278, 0), background=(0, 0, 0))
+    cam3 = rl.CameraParams(aspect_ratio=1.5, image_width=96, samples_per_pixel=66, max_depth=10, vfov=50.0, lookfrom=(0, 0.5, 1.0), lookat=(0, 0, -3), background=(0.6, 0.7, 0.9), seed=9)
+    cow = rl.World.cow_scene(golden("spot_triangulated.obj.gz"), tex)
+    pc = cow.params
+    pc.aspect_ratio, pc.image_width, pc.samples_per_pixel = 16.0 / 9.0, 128, 8
+    stress = rl.World.stress_scene(60, 1, golden("spot_triangulated.obj.gz"), tex)
+    ps = stress.params
+    ps.image_width, ps.samples_per_pixel, ps.max_depth = 128, 4, 50
+    earth = rl.World.earth_scene(tex)
+    pe = earth.params
+    pe.image_width, pe.samples_per_pixel, pe.max_depth = 96, 6, 20
+    return [("composed", rl.World.build(composed), cam1), ("cornell", rl.World.build(cornell), cam2), ("instanced_twice", rl.World.build(instanced_twice), cam3),
+            ("cow", cow, pc), ("stress", stress, ps), ("earth", earth, pe), ("perlin", rl.World.perlin_spheres(), None), ("simple_light", rl.World.simple_light(), None)]
+
+
+def test_general_scenes_fast_traversal_equals_reference_order_and_oracle(rl, oracle, golden):
+    """Planars, Translate / Transform chains, image / noise textures, a mesh instanced twice, coincident quads, the cfg-4 and cfg-5
+    generators: the fast world-space traversal renders the reference-order kernels' frames bit for bit."""
+    report = {}
+    for name, world, p in _general_scenes(rl, golden):
+        if p is None:
+            p = world.params
+            p.image_width, p.samples_per_pixel, p.max_depth = 96, 6, 20
+        cam = rl.Camera(p)
+        fast, ref_order, counting, st, gs = _frames(rl, cam, world)
+        assert _same_bits(fast, ref_order) and _same_bits(fast, counting), name
+        cs = {}
+        cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+        for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
+            assert gs[k] == cs[k], (name, k, gs[k], cs[k])
+        assert np.abs(fast - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max()), name
+        report[name] = (st["slow_traces"], st["rays"])
+    print(report)
+    assert report["cornell"][0] > 0                       # the coincident quads tie
+    assert report["cow"][0] * 1000 < report["cow"][1]     # and the BASELINE scenes almost never fall back
+    assert report["stress"][0] * 200 < report["stress"][1]

@@ -2,6 +2,7 @@
 each with a row-subsampled parity check against the CPU oracle.  Prints one JSON line per config."""
 import gzip, importlib, json, os, sys, time
 import numpy as np
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 rl = importlib.import_module("rendering-learning_amd")
@@ -14,6 +15,8 @@ which = sys.argv[1:] or ["cfg3", "cfg4", "cfg5"]
 
 
 def rtiow(name, world, p, check_step):
+    """Counting render (the reference's counters) + the TIMED counter-free render (what a host calls: the fast traversal where the
+    scene qualifies), HIP events on the launch stream; the timed frame must equal the counting frame bit for bit."""
     cam = rl.Camera(p)
     st = {}
     warm = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": 1}))
@@ -21,14 +24,30 @@ def rtiow(name, world, p, check_step):
     t0 = time.perf_counter()
     gpu = cam.render(world, stats=st).data
     wall = time.perf_counter() - t0
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros((cam.c.image_height, cam.c.image_width, 3), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    warm.render_device(world, buf.data_ptr(), stream=stream.cuda_stream)
+    rl.api.render_status(world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    cam.render_device(world, buf.data_ptr(), stream=stream.cuda_stream)
+    e1.record(stream)
+    status = rl.api.render_status(world)
+    torch.cuda.synchronize(dev)
+    timed_ms = e0.elapsed_time(e1)
+    timed = buf.cpu().numpy()
     cs = {}
     cpu = oracle.rtiow_render(world.desc, cam.c, row_first=0, row_step=check_step, stats=cs)
-    err = float(np.abs(gpu[0::check_step] - cpu).max()) / p.samples_per_pixel
+    err = float(np.abs(timed[0::check_step] - cpu).max()) / p.samples_per_pixel
     alg = 64 * st["node_tests"] + 64 * st["sphere_tests"] + 128 * st["planar_tests"] + 216 * st["instance_enters"] + 208 * st["rays"]
     print(json.dumps({"config": name, "W": cam.c.image_width, "H": cam.c.image_height, "spp": p.samples_per_pixel, "depth": p.max_depth,
-                      "rays": st["rays"], "kernel_ms": st["kernel_ms"], "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
-                      "per_ray": {k: st[k] / st["rays"] for k in ("node_tests", "sphere_tests", "planar_tests", "instance_enters")},
-                      "alg_GBps": alg / st["kernel_ms"] / 1e6, "max_abs_err_vs_oracle_rows": err, "oracle_rows_step": check_step, "wall_s": wall}), flush=True)
+                      "rays": st["rays"], "timed_kernel_ms": timed_ms, "Mrays_s": st["rays"] / timed_ms / 1e3,
+                      "timed_frame_equals_counting_frame": bool(np.array_equal(timed, gpu)), "timed_rays_equal": status["rays"] == st["rays"],
+                      "slow_traces": status["slow_traces"],
+                      "counting_kernel_ms": st["kernel_ms"], "counting_Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
+                      "per_ray_reference_counts": {k: st[k] / st["rays"] for k in ("node_tests", "sphere_tests", "planar_tests", "instance_enters")},
+                      "alg_GBps": alg / timed_ms / 1e6, "max_abs_err_vs_oracle_rows": err, "oracle_rows_step": check_step, "wall_s": wall}), flush=True)
 
 
 if "cfg3" in which:
