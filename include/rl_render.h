@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 4
+#define RL_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ errors */
 #define RL_OK 0
@@ -94,7 +94,8 @@ enum {
   RL_H_TRANSLATE = 3, /* hittable/translate.rs:6 */
   RL_H_TRANSFORM = 4, /* hittable/transform.rs:13 */
   RL_H_BVH = 5,       /* bvh.rs:11 Bvh<H> node */
-  RL_H_LIST = 6       /* hittable/mod.rs:88 impl Hittable for [H] */
+  RL_H_LIST = 6,      /* hittable/mod.rs:88 impl Hittable for [H] */
+  RL_H_MEDIUM = 7     /* hittable/constant_medium.rs:9 ConstantMedium (deterministic variant, see rl_medium) */
 };
 
 typedef struct rl_sphere { /* sphere.rs:11-21 */
@@ -136,6 +137,19 @@ typedef struct rl_bvh_node { /* bvh.rs:11-20 */
   rl_href child[2];
 } rl_bvh_node;
 
+/* hittable/constant_medium.rs:9-80 with ONE deliberate difference: the reference draws the free path from the process-global
+ * `rand::random::<f64>()` (constant_medium.rs:55; its own comment: "This breaks deterministic/repeatable renders"), which no seeded
+ * reference run can reproduce.  Here the draw comes from the pixel's ChaCha8 stream — the `rng` Camera::_render hands to scatter —
+ * at the moment ConstantMedium::hit reaches it, in the reference's evaluation order: hit_distance = neg_inv_density * ln(gen::<f64>()).
+ * Everything else is the reference's: boundary.hit(r, universe), boundary.hit(r, [t1 + 1e-4, inf]), clamping to ray_t, the arbitrary
+ * normal (1, 0, 0) / uv (0, 0) / Face::Front.  The boundary may be any hittable except another medium. */
+typedef struct rl_medium {
+  rl_href boundary;
+  double neg_inv_density; /* -1.0 / density (constant_medium.rs:19) */
+  uint32_t material;      /* phase function: meant to be RL_MAT_ISOTROPIC */
+  uint32_t reserved;
+} rl_medium;
+
 typedef struct rl_list { /* a slice of hittables; items live in list_items[first .. first+count) */
   uint32_t first, count;
 } rl_list;
@@ -145,7 +159,8 @@ enum {
   RL_MAT_LAMBERTIAN = 1, /* material.rs:69 */
   RL_MAT_METAL = 2,      /* material.rs:99 */
   RL_MAT_DIELECTRIC = 3, /* material.rs:134 */
-  RL_MAT_DIFFUSE_LIGHT = 4 /* material.rs:178 */
+  RL_MAT_DIFFUSE_LIGHT = 4, /* material.rs:178 */
+  RL_MAT_ISOTROPIC = 5      /* material.rs:197: scatters into Vec3::random_unit_vector, attenuation = texture (uses `texture`) */
 };
 typedef struct rl_material {
   uint32_t kind;
@@ -188,6 +203,7 @@ typedef struct rl_rtiow_scene_desc {
   const rl_image *images;         uint32_t n_images;
   rl_href root;
   const rl_perlin *perlins;       uint32_t n_perlins; /* ABI v3 */
+  const rl_medium *media;         uint32_t n_media;   /* ABI v5 */
 } rl_rtiow_scene_desc;
 
 /* The DERIVED camera: outputs of Camera::new (camera.rs:72-118). The host keeps Camera::new

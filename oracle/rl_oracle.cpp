@@ -147,10 +147,13 @@ struct HitRecord {  // hittable/mod.rs:24-30
 struct Counters {
   uint64_t rays = 0, node_tests = 0, sphere_tests = 0, planar_tests = 0, instance_enters = 0, rng_words = 0, flagged = 0;
 };
+struct ChaCha8;
 struct RtiowCtx {
   const rl_rtiow_scene_desc *d;
   Counters c;
+  ChaCha8 *rng = nullptr;  // the pixel's stream: only ConstantMedium::hit (deterministic variant, rl_render.h rl_medium) draws while traversing
 };
+double medium_draw(RtiowCtx &cx);
 
 // float-cmp approx_eq(a, b, F64Margin{epsilon, ulps}) == (a==b || |a-b|<=eps || ulps_diff<=ulps)
 inline bool approx_eq_eps(double a, double b, double eps) { return a == b || std::fabs(a - b) <= eps; }
@@ -302,6 +305,24 @@ bool hit_href(RtiowCtx &cx, rl_href h, const Ray &r, double tmin, double tmax, H
       cx.c.node_tests++;
       if (!aabb_hit(n.bbox, r, tmin, tmax)) return false;
       return hit_slice(cx, n.child, n.n_children, r, tmin, tmax, rec);
+    }
+    case RL_H_MEDIUM: {  // constant_medium.rs:27-80; the free path is drawn from the pixel's stream instead of rand::random (:55)
+      if (h.index >= d.n_media || !cx.rng) return false;
+      const rl_medium &m = d.media[h.index];
+      const double INF = std::numeric_limits<double>::infinity();
+      HitRecord rec1, rec2;
+      if (!hit_href(cx, m.boundary, r, -INF, INF, rec1)) return false;              // boundary.hit(r, &Interval::universe())
+      if (!hit_href(cx, m.boundary, r, rec1.t + 1e-4, INF, rec2)) return false;     // ... min: rec1.t + 1e-4
+      double t1 = std::fmax(rec1.t, tmin), t2 = std::fmin(rec2.t, tmax);             // f64::max / f64::min
+      if (t1 >= t2) return false;
+      t1 = std::fmax(t1, 0.0);
+      double ray_length = std::sqrt(len2(r.d));                                      // Vec3::length
+      double distance_inside_boundary = (t2 - t1) * ray_length;
+      double hit_distance = m.neg_inv_density * std::log(medium_draw(cx));
+      if (hit_distance > distance_inside_boundary) return false;
+      double t = t1 + hit_distance / ray_length;
+      rec.t = t, rec.p = r.at(t), rec.normal = V3{1.0, 0.0, 0.0}, rec.u = 0.0, rec.v = 0.0, rec.front = true, rec.mat = m.material;
+      return true;
     }
     case RL_H_TRANSLATE: {  // translate.rs:14-21
       const rl_translate &t = d.translates[h.index];
@@ -465,6 +486,11 @@ bool scatter(RtiowCtx &cx, ChaCha8 &rng, const rl_material &m, const Ray &ray, c
       att = V3{1.0, 1.0, 1.0};
       return true;
     }
+    case RL_MAT_ISOTROPIC: {  // material.rs:201-214
+      out = Ray{rec.p, rng.unit_sphere(), ray.time};
+      att = texture_value(*cx.d, m.texture, rec.u, rec.v, rec.p);
+      return true;
+    }
     default:  // Flat, DiffuseLight: no scatter
       return false;
   }
@@ -494,10 +520,13 @@ V3 ray_color(RtiowCtx &cx, const rl_rtiow_camera &cam, ChaCha8 &rng, const Ray &
   return v3(cam.background);
 }
 
+double medium_draw(RtiowCtx &cx) { return cx.rng->gen_f64(); }
+
 void rtiow_pixel(RtiowCtx &cx, const rl_rtiow_camera &cam, uint64_t first_sample, uint32_t i, uint32_t j, double out[3]) {
   // camera.rs:160-175
   ChaCha8 rng;
   rng.seed_from_u64(cam.seed);
+  cx.rng = &rng;
   const uint64_t W = cam.image_width, H = cam.image_height;
   V3 p00 = v3(cam.pixel_00), du = v3(cam.pixel_du), dv = v3(cam.pixel_dv);
   V3 sum{0.0, 0.0, 0.0};
@@ -524,6 +553,7 @@ void rtiow_pixel(RtiowCtx &cx, const rl_rtiow_camera &cam, uint64_t first_sample
     sum = sum + c;
   }
   cx.c.rng_words += rng.words_drawn;
+  cx.rng = nullptr;
   out[0] = sum.x, out[1] = sum.y, out[2] = sum.z;
 }
 

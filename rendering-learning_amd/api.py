@@ -84,7 +84,7 @@ RTC_CSG = np.dtype([("operation", "<u4"), ("reserved", "<u4"), ("left", HREF), (
 RTC_PATTERN = np.dtype([("kind", "<u4"), ("reserved", "<u4"), ("a", "<f8", 3), ("b", "<f8", 3), ("inverse", "<f8", 16)])
 RTC_LIGHT = np.dtype([("position", "<f8", 3), ("intensity", "<f8", 3)])
 
-MAT_FLAT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3, 4
+MAT_FLAT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4, 5
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE, TEX_NOISE = 0, 1, 2, 3
 O_TRIANGLE, O_GROUP, O_BOUNDED, O_TRANSFORMED, O_SPHERE, O_PLANE, O_CUBE, O_CYLINDER, O_CONE, O_CSG = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = 0, 1, 2
@@ -409,6 +409,7 @@ class SceneBuilder:
                      ("rlh_b_planar", [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
                      ("rlh_b_triangle", [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
                      ("rlh_b_translate", [C.c_void_p, C.c_int, C.c_void_p]),
+                     ("rlh_b_medium", [C.c_void_p, C.c_int, C.c_double, C.c_int]),
                      ("rlh_b_transform", [C.c_void_p, C.c_int, C.c_int, C.c_double]),
                      ("rlh_b_group", [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]),
                      ("rlh_b_obj", [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]),
@@ -457,6 +458,13 @@ class SceneBuilder:
 
     def flat(self):
         return self._chk(self._L.rlh_b_material(self._b, MAT_FLAT, -1, None, 0.0, 1.0))
+
+    def isotropic(self, tex):
+        return self._chk(self._L.rlh_b_material(self._b, MAT_ISOTROPIC, tex, None, 0.0, 1.0))
+
+    def constant_medium(self, boundary, density, mat):
+        """ConstantMedium::new(boundary, density, phase_function) — deterministic variant (rl_render.h rl_medium)."""
+        return self._chk(self._L.rlh_b_medium(self._b, boundary, density, mat))
 
     def sphere(self, center, radius, mat, center2=None):
         c0, c1 = self._v(center), self._v(center2)

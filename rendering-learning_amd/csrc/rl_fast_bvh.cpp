@@ -241,6 +241,7 @@ struct GItem {
 
 bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out) {
   out = FastGeneral{};
+  if (rt.has_media) return false;  // a ConstantMedium draws from the RNG while the world is traversed: the reference's order is part of its result
   const std::vector<DevOp> &ops = rt.ops;
   // ---- matrices: finite, bounded norm (an instance normal M^-T n of a unit n then has |.|^2 >= 1 / (3 |M|_inf^2) >> 1e-16)
   for (uint32_t i = 0; i < d.n_transforms; i++) {

@@ -17,6 +17,7 @@ struct RtiowCompiler {
   std::string &err;
   std::vector<uint8_t> bvh_busy, list_busy, tr_busy, tf_busy;
   std::vector<uint32_t> push_stack;
+  bool in_medium = false;
 
   bool fail(const std::string &m) {
     err = m;
@@ -30,6 +31,7 @@ struct RtiowCompiler {
       case RL_H_TRANSFORM: return h.index < d.n_transforms || fail("transform index out of range");
       case RL_H_BVH: return h.index < d.n_bvh_nodes || fail("bvh node index out of range");
       case RL_H_LIST: return h.index < d.n_lists || fail("list index out of range");
+      case RL_H_MEDIUM: return h.index < d.n_media || fail("medium index out of range");
       default: return fail("unknown hittable kind");
     }
   }
@@ -107,6 +109,25 @@ struct RtiowCompiler {
         p.ops[idx].skip = (uint32_t)p.ops.size();
         return true;
       }
+      case RL_H_MEDIUM: {  // constant_medium.rs: the boundary is evaluated by itself (twice per ray), not folded into the world
+        if (in_medium) return fail("a ConstantMedium boundary must not contain another medium");
+        const rl_medium &m = d.media[h.index];
+        if (m.material >= d.n_materials) return fail("medium material out of range");
+        uint32_t begin = (uint32_t)p.ops.size();
+        DevOp op{};
+        op.code = OP_MEDIUM_BEGIN, op.a = h.index, op.b = NONE;
+        p.ops.push_back(op);
+        in_medium = true;
+        if (!emit(m.boundary, depth + 1)) return false;
+        in_medium = false;
+        DevOp e{};
+        e.code = OP_MEDIUM_END, e.a = h.index, e.b = begin;
+        e.skip = (uint32_t)p.ops.size() + 1;
+        p.ops.push_back(e);
+        p.ops[begin].skip = (uint32_t)p.ops.size();
+        p.has_media = true;
+        return true;
+      }
       case RL_H_TRANSLATE:
       case RL_H_TRANSFORM: {
         bool tr = h.kind == RL_H_TRANSLATE;
@@ -153,8 +174,10 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
   if (!need(d.spheres, d.n_spheres, "spheres") || !need(d.planars, d.n_planars, "planars") || !need(d.translates, d.n_translates, "translates") ||
       !need(d.transforms, d.n_transforms, "transforms") || !need(d.bvh_nodes, d.n_bvh_nodes, "bvh_nodes") || !need(d.lists, d.n_lists, "lists") ||
       !need(d.list_items, d.n_list_items, "list_items") || !need(d.materials, d.n_materials, "materials") ||
-      !need(d.textures, d.n_textures, "textures") || !need(d.images, d.n_images, "images") || !need(d.perlins, d.n_perlins, "perlins"))
+      !need(d.textures, d.n_textures, "textures") || !need(d.images, d.n_images, "images") || !need(d.perlins, d.n_perlins, "perlins") ||
+      !need(d.media, d.n_media, "media"))
     return RL_E_INVALID;
+  for (uint32_t i = 0; i < d.n_media; i++) p.media.push_back(d.media[i]);
   if (d.n_spheres > SPH_INDEX) {
     err = "too many spheres";
     return RL_E_INVALID;
@@ -231,11 +254,11 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
   }
   for (uint32_t i = 0; i < d.n_materials; i++) {
     const rl_material &m = d.materials[i];
-    if (m.kind > RL_MAT_DIFFUSE_LIGHT) {
+    if (m.kind > RL_MAT_ISOTROPIC) {
       err = "unknown material kind";
       return RL_E_INVALID;
     }
-    if ((m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) && m.texture >= d.n_textures) {
+    if ((m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT || m.kind == RL_MAT_ISOTROPIC) && m.texture >= d.n_textures) {
       err = "material texture out of range";
       return RL_E_INVALID;
     }
@@ -245,7 +268,7 @@ int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &p, std::string &er
   std::vector<uint8_t> mat_uv(d.n_materials, 0);
   for (uint32_t i = 0; i < d.n_materials; i++) {
     const rl_material &m = d.materials[i];
-    if (m.kind != RL_MAT_LAMBERTIAN && m.kind != RL_MAT_DIFFUSE_LIGHT) continue;
+    if (m.kind != RL_MAT_LAMBERTIAN && m.kind != RL_MAT_DIFFUSE_LIGHT) continue;  // (an Isotropic's hit record carries uv (0, 0))
     std::vector<uint32_t> st{m.texture};
     std::vector<uint8_t> seen(d.n_textures, 0);
     while (!st.empty()) {

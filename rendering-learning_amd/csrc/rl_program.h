@@ -27,6 +27,8 @@ enum : uint32_t {
   OP_POP_TRANSLATE = 7,
   OP_PUSH_TRANSFORM = 8,
   OP_POP_TRANSFORM = 9,
+  OP_MEDIUM_BEGIN = 10,  // ConstantMedium a: the boundary's ops follow up to the matching OP_MEDIUM_END at `skip` - 1; next = skip
+  OP_MEDIUM_END = 11,    // b = pc of the matching OP_MEDIUM_BEGIN (never stepped by the world traversal)
 };
 static const uint32_t BOX_FINITE = 0x100u;  // flag OR-ed into a box op's code: all six bounds finite, |b| <= 1e100
 static const uint32_t NONE = 0xFFFFFFFFu;
@@ -104,8 +106,9 @@ struct RtiowProgram {
   std::vector<DevImage> images;
   std::vector<float> image_pool;
   std::vector<rl_perlin> perlins;
+  std::vector<rl_medium> media;
   std::vector<uint8_t> sphere_uv;  // per sphere: texture tree reaches an Image
-  bool has_planars = false, has_instances = false, has_images = false, has_noise = false, has_sphere_uv = false;
+  bool has_planars = false, has_instances = false, has_images = false, has_noise = false, has_sphere_uv = false, has_media = false;
   uint32_t max_instance_depth = 0;
 };
 

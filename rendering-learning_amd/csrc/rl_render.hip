@@ -191,7 +191,7 @@ int rl_device_info(char *name, int cap) {
 static void destroy_one(rl_scene *s) {
   if ((size_t)s->ctx < g_ctx.size()) hipSetDevice(g_ctx[(size_t)s->ctx].device);
   hipFree(s->d_ops), hipFree(s->d_lops), hipFree(s->d_sphere_flat), hipFree(s->d_cops), hipFree(s->d_movbits), hipFree(s->d_spheres), hipFree(s->d_sphere_material), hipFree(s->d_planars), hipFree(s->d_translates);
-  hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins);
+  hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
   hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items);
@@ -346,7 +346,7 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
   std::string err;
   if (compile_rtiow(*desc, H->rt, err) != RL_OK) return set_err(RL_E_INVALID, err);
   const RtiowProgram &rt = H->rt;
-  if (!(rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise) && rt.ops.size() < (1u << 29)) {
+  if (!(rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media) && rt.ops.size() < (1u << 29)) {
     H->entry0 = link_ops(rt.ops, H->lops);
     flatten_sphere_materials(rt, H->sphere_flat);
     // compact guarded form (32-byte ops: binary32 box + the two successor words) for the 4-waves-per-SIMD layout
@@ -391,7 +391,8 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
   if ((rc = upload(rt.ops, &s->d_ops)) || (rc = upload(rt.spheres, &s->d_spheres)) || (rc = upload(rt.sphere_material, &s->d_sphere_material)) ||
       (rc = upload(rt.planars, &s->d_planars)) || (rc = upload(rt.translates, &s->d_translates)) || (rc = upload(rt.transforms, &s->d_transforms)) ||
       (rc = upload(rt.materials, &s->d_materials)) || (rc = upload(rt.textures, &s->d_textures)) || (rc = upload(rt.images, &s->d_images)) ||
-      (rc = upload(rt.image_pool, &s->d_image_pool)) || (rc = upload(rt.perlins, &s->d_perlins)) || (rc = scene_common(s)) ||
+      (rc = upload(rt.image_pool, &s->d_image_pool)) || (rc = upload(rt.perlins, &s->d_perlins)) || (rc = upload(rt.media, &s->d_media)) ||
+      (rc = scene_common(s)) ||
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes))) ||
@@ -564,7 +565,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   RtiowParams P{};
   P.ops = scene->d_ops, P.spheres = scene->d_spheres, P.sphere_material = scene->d_sphere_material;
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
-  P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins;
+  P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins, P.media = scene->d_media;
   P.n_ops = (uint32_t)rt.ops.size(), P.n_spheres = (uint32_t)rt.spheres.size();
   P.lops = scene->d_lops, P.entry0 = H.entry0, P.sphere_flat = scene->d_sphere_flat;
   const uint32_t n_cops = (uint32_t)H.cops.size();
@@ -616,7 +617,10 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
-  bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise;
+  bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
+  // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: only the nested-loop all-primitives kernel
+  // evaluates it (reference order by construction); no fast traversal, no cost-sorted resume
+  if (rt.has_media) variant = 2;
 #ifndef RL_EXPERIMENTAL
   if (variant == 3 || variant == 5 || variant == 6 || variant == 7) return set_err(RL_E_UNSUPPORTED, "experimental kernel variants live in librl_render_exp.so only");
 #endif
@@ -669,11 +673,17 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       constexpr int NT = 256;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
-    } else if (variant == 1031) {  // rings + the traversal stacks in LDS (288 B per lane): 512 lanes per CU
-      constexpr int NT = 512;
-      size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + FASTG_MAX_DEPTH * sizeof(uint32_t));
+    } else if (variant == 1031) {  // rings + the traversal stacks in LDS
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      rc = trans ? launch(rtiow_fast_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_fast_general_kernel<NT, false>, NT, rb, false);
+      if (trans || std::getenv("RL_FASTG512")) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
+        constexpr int NT = 512, SD = 40;
+        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        rc = trans ? launch(rtiow_fast_general_kernel<NT, SD, true>, NT, rb, false) : launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+      } else {  // 768 lanes per CU (3 waves per SIMD hide more of the node-fetch latency), 20-entry stacks: 208 B of LDS per lane
+        constexpr int NT = 768, SD = 20;
+        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        rc = launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+      }
     } else if (variant == 4) {
       // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of
       // scenes that have Noise textures or Image textures on spheres).  At 768 lanes (168 VGPRs) the spills land in the TRAV
@@ -828,6 +838,10 @@ void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
 int rl_debug_fastg_verify(unsigned int *count, double *log768) {
   HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(rl::g_vcount), 4));
   HIP_TRY(hipMemcpyFromSymbol(log768, HIP_SYMBOL(rl::g_vlog), 64 * 12 * 8));
+  return RL_OK;
+}
+int rl_debug_fastg_counts(unsigned long long *out4) {
+  HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(rl::g_vstats), 32));
   return RL_OK;
 }
 #endif

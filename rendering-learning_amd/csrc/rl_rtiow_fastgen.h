@@ -90,6 +90,7 @@ __device__ __forceinline__ uint32_t general_slow_trace(const RtiowParams &P, con
 #ifdef RL_FASTG_VERIFY  // debug build (tools/verify_fastg.py): every ray is ALSO traced in the reference's order; mismatches are logged
 __device__ unsigned int g_vcount;
 __device__ double g_vlog[64][12];
+__device__ unsigned long long g_vstats[4];  // TRAV steps, LEAF visits, far-origin rays
 #endif
 // Sphere::hit / Plane::hit_ab for the ROOT only, acceptance window widened by the tie band (see fast_sphere_hit in rl_rtiow_wave.h)
 __device__ __forceinline__ void fastg_planar_hit(const DevPlanar &pl, D3 o, D3 d, float oimax, uint32_t item, double &closest, uint32_t &best, bool &amb) {
@@ -150,12 +151,14 @@ __device__ __forceinline__ void fastg_sphere_hit(const DevSphere &s, uint32_t pa
   if (t <= closest) closest = t, best = item;
 }
 
-template <int NT, bool TRANS>
+// SD = entries of the per-lane LDS stack (a deeper pending list re-traces the ray in the reference's order: the tree may be 40 deep,
+// the list of pending far children hardly ever is)
+template <int NT, int SD, bool TRANS>
 __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;                                   // [16][NT]
-  uint32_t *s_stack = (uint32_t *)(smem + (size_t)16 * NT * sizeof(unsigned long long));  // [FASTG_MAX_DEPTH][NT]
+  uint32_t *s_stack = (uint32_t *)(smem + (size_t)16 * NT * sizeof(unsigned long long));  // [SD][NT]
   const DevOp *ops = P.ops;
   const FastNodeG *nodes = P.fg_nodes;
   const FastItem *items = P.fg_items;
@@ -184,6 +187,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
   float grow = 0.0f;
   bool unsafe = false;
   uint32_t c_rays = 0, c_flag = 0, c_slow = 0;
+#ifdef RL_FASTG_VERIFY
+  unsigned long long c_steps = 0, c_leaves = 0, c_unsafe = 0;
+#endif
 
   auto go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), an item (LEAF), or nothing left (SHADE)
     if (e == NONE) {
@@ -214,6 +220,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
     amb = !(ra32.slack < FINF);  // outside the binary32 filter's range: the reference's order
     unsafe = !(far2 <= P.fg_rsafe2);
     grow = 0.0f;
+#ifdef RL_FASTG_VERIFY
+    c_unsafe += unsafe ? 1u : 0u;
+#endif
     if (unsafe) {  // pad(L) = fg_pad_k * L^2 in world units (rl_fast_bvh.cpp), L = distance to the centre + the scene's radius; in units of t: / min |d_k|
       float L = sqrtf(far2) + P.fg_radius;
       grow = P.fg_pad_k * L * L * fmaxf(fmaxf(fabsf(ra32.invx), fabsf(ra32.invy)), fabsf(ra32.invz));
@@ -241,6 +250,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
       int floor_n = (bestn * (int)P.tune[1]) >> 4;
       for (int it = 0; it < (int)P.tune[0]; it++) {
         if (state == ST_TRAV) {
+#ifdef RL_FASTG_VERIFY
+          c_steps++;
+#endif
           const Float4 *nd = (const Float4 *)(nodes + pc);
           const Float4 q0 = nd[0], q1 = nd[1], q2 = nd[2];
           const uint2 ch = *(const uint2 *)((const unsigned char *)(nodes + pc) + 48);
@@ -261,8 +273,8 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
           const bool a_first = hitA && (!hitB || tA <= tB);
           uint32_t first = a_first ? ch.x : ch.y;
           if (hitA && hitB) {
-            if (sp < FASTG_MAX_DEPTH) s_stack[(size_t)sp * NT + tid] = a_first ? ch.y : ch.x, sp++;
-            else amb = true;  // cannot happen for a tree build_fast_general made (depth <= FASTG_MAX_DEPTH)
+            if (sp < (uint32_t)SD) s_stack[(size_t)sp * NT + tid] = a_first ? ch.y : ch.x, sp++;
+            else amb = true;  // more pending far children than the stack holds: the reference's order decides
           }
           if (!(hitA || hitB)) first = pop();
           go(first);
@@ -271,6 +283,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
       }
     } else if (pick == ST_LEAF) {
       if (state == ST_LEAF) {
+#ifdef RL_FASTG_VERIFY
+        c_leaves++;
+#endif
         const uint32_t item = pc & ~FASTG_LEAF;
         const FastItem it = items[item];
         D3 o, d;
@@ -515,6 +530,14 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
   if ((tid & 63) == 0 && v) atomicAdd(&P.stats[6], v);
   v = wave_sum((unsigned long long)c_slow);
   if ((tid & 63) == 0 && v) atomicAdd(&P.stats[7], v);
+#ifdef RL_FASTG_VERIFY
+  v = wave_sum(c_steps);
+  if ((tid & 63) == 0) atomicAdd(&g_vstats[0], v);
+  v = wave_sum(c_leaves);
+  if ((tid & 63) == 0) atomicAdd(&g_vstats[1], v);
+  v = wave_sum(c_unsafe);
+  if ((tid & 63) == 0) atomicAdd(&g_vstats[2], v);
+#endif
 }
 
 }  // namespace rl

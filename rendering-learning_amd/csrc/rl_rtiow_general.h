@@ -42,7 +42,8 @@ __device__ __forceinline__ void face_normal(D3 d, D3 outward, D3 &normal, bool &
 }
 
 // Sphere::hit with the full record (sphere.rs:32-75); returns the from_normalized flag
-__device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payload, uint32_t mat, uint32_t pc, D3 o, D3 d, double time, Rec &r) {
+__device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payload, uint32_t mat, uint32_t pc, D3 o, D3 d, double time, Rec &r,
+                                               double tmin = 1e-10) {
   D3 c0 = ld3(s.c0);
   D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
   D3 oc = o - center;
@@ -55,8 +56,8 @@ __device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payl
   double r_l = (-half_b - sq) / a;
   double r_u = (-half_b + sq) / a;
   double t;
-  if (1e-10 <= r_l && r_l <= r.t) t = r_l;
-  else if (1e-10 <= r_u && r_u <= r.t) t = r_u;
+  if (tmin <= r_l && r_l <= r.t) t = r_l;
+  else if (tmin <= r_u && r_u <= r.t) t = r_u;
   else return false;
   D3 p = o + d * t;
   D3 outward = (p - center) * s.inv_r;
@@ -71,12 +72,12 @@ __device__ __forceinline__ bool sphere_hit_rec(const DevSphere &s, uint32_t payl
 }
 
 // Plane::hit_ab + Plane/Quad/Triangle::hit (plane.rs:51-100, quad.rs:37-42, triangle.rs:60-95); returns flag
-__device__ __forceinline__ bool planar_hit_rec(const DevPlanar &pl, uint32_t pc, D3 o, D3 d, Rec &r) {
+__device__ __forceinline__ bool planar_hit_rec(const DevPlanar &pl, uint32_t pc, D3 o, D3 d, Rec &r, double tmin = 1e-10) {
   D3 normal = ld3(pl.normal);
   double denom = dot(normal, d);
   if (fabs(denom) < 1e-8) return false;
   double t = (pl.d - dot(normal, o)) / denom;
-  if (!(1e-10 <= t && t <= r.t)) return false;
+  if (!(tmin <= t && t <= r.t)) return false;
   D3 p = o + d * t;
   D3 hp = p - ld3(pl.q);
   D3 w = ld3(pl.w);
@@ -133,6 +134,138 @@ __device__ __forceinline__ void replay_chain(const RtiowParams &P, const DevOp *
   }
 }
 
+struct GenCounters {
+  unsigned long long nodes, spheres, planars, instances, flagged;
+};
+
+// The reference's fold over ops [pc, pc_end) (pc_end == NONE: up to OP_END): bvh.rs:79-95, hittable/mod.rs:88-111,
+// transform.rs:143-164, translate.rs:14-21 with ray_t = [tmin, rec.t]; (o, d) = the ray in the scope the range starts in,
+// (wo, wd) = the world ray (POP ops restore the parent-scope ray by replaying the PUSH chain from it).
+// MEDIA: ConstantMedium ops are evaluated (constant_medium.rs:27-80, deterministic variant of include/rl_render.h rl_medium:
+// `draw()` supplies gen::<f64>() from the pixel's ChaCha8 stream); their boundaries run through this function with MEDIA = false.
+template <bool STATS, bool MEDIA, class Draw>
+__device__ __forceinline__ void general_trace(const RtiowParams &P, const DevOp *ops, uint32_t pc, uint32_t pc_end, D3 o, D3 d, D3 wo, D3 wd, double time,
+                                              double tmin, Rec &rec, GenCounters &gc, Draw &draw) {
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  RayAux ra = ray_aux(o, d);
+#pragma unroll 1
+  for (;;) {
+    if (pc == pc_end) break;
+    const DevOp &op = ops[pc];
+    uint32_t code = op.code & 0xFFu;
+    if (code == OP_END) break;
+    if (code == OP_BOX || code == OP_BOX_SPH || code == OP_BOX_PLANAR) {
+      if (STATS) gc.nodes++;
+      double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
+      bool hitb;
+      if (tmin == 1e-10) {  // the filtered test is derived for the world interval [1e-10, closest]
+        bool certain;
+        hitb = aabb_fast(bx, ra, rec.t, certain);
+        if (!(certain && ra.fast_ok && (op.code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, rec.t);  // rare: the reference's divisions
+      } else hitb = aabb_hit(bx, o, d, tmin, rec.t);
+      if (!hitb) {
+        pc = op.skip;
+        continue;
+      }
+      if (code == OP_BOX) {
+        pc++;
+        continue;
+      }
+      uint32_t a = op.a, b = op.b;
+      if (code == OP_BOX_SPH) {
+        if (STATS) gc.spheres++;
+        uint32_t ai = a & SPH_INDEX;
+        if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec, tmin)) gc.flagged++;
+        if (b != NONE) {
+          if (STATS) gc.spheres++;
+          uint32_t bi = b & SPH_INDEX;
+          if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec, tmin)) gc.flagged++;
+        }
+      } else {
+        if (STATS) gc.planars++;
+        if (planar_hit_rec(P.planars[a], pc, o, d, rec, tmin)) gc.flagged++;
+        if (b != NONE) {
+          if (STATS) gc.planars++;
+          if (planar_hit_rec(P.planars[b], pc, o, d, rec, tmin)) gc.flagged++;
+        }
+      }
+      pc = op.skip;
+      continue;
+    }
+    if (code == OP_SPHERE) {
+      if (STATS) gc.spheres++;
+      uint32_t a = op.a, ai = a & SPH_INDEX;
+      if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec, tmin)) gc.flagged++;
+      pc++;
+      continue;
+    }
+    if (code == OP_PLANAR) {
+      if (STATS) gc.planars++;
+      if (planar_hit_rec(P.planars[op.a], pc, o, d, rec, tmin)) gc.flagged++;
+      pc++;
+      continue;
+    }
+    if (code == OP_PUSH_TRANSLATE) {  // translate.rs:15
+      if (STATS) gc.instances++;
+      o = o - ld3(P.translates[op.a].offset);
+      ra = ray_aux(o, d);
+      pc++;
+      continue;
+    }
+    if (code == OP_PUSH_TRANSFORM) {  // transform.rs:145-149
+      if (STATS) gc.instances++;
+      const rl_transform &t = P.transforms[op.a];
+      D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
+      o = no, d = nd;
+      ra = ray_aux(o, d);
+      pc++;
+      continue;
+    }
+    if (code == OP_MEDIUM_BEGIN) {
+      if (MEDIA) {  // constant_medium.rs:27-80
+        const rl_medium &m = P.media[op.a];
+        const uint32_t b0 = pc + 1, b1 = op.skip - 1;  // the boundary's ops; ops[b1] = OP_MEDIUM_END
+        Rec r1, r2;
+        r1.t = INF, r1.any = false, r1.pc = 0, r2.t = INF, r2.any = false, r2.pc = 0;
+        general_trace<STATS, false>(P, ops, b0, b1, o, d, wo, wd, time, -INF, r1, gc, draw);  // boundary.hit(r, universe)
+        if (r1.any) general_trace<STATS, false>(P, ops, b0, b1, o, d, wo, wd, time, r1.t + 1e-4, r2, gc, draw);
+        if (r1.any && r2.any) {
+          double t1 = fmax(r1.t, tmin), t2 = fmin(r2.t, rec.t);
+          if (!(t1 >= t2)) {
+            t1 = fmax(t1, 0.0);
+            double ray_length = sqrt(len2(d));
+            double distance_inside_boundary = (t2 - t1) * ray_length;
+            double hit_distance = m.neg_inv_density * log(draw());
+            if (!(hit_distance > distance_inside_boundary)) {
+              double t = t1 + hit_distance / ray_length;
+              rec.t = t, rec.p = o + d * t, rec.normal = d3(1.0, 0.0, 0.0), rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false;
+              rec.front = true, rec.mat = m.material, rec.pc = pc, rec.any = true;
+            }
+          }
+        }
+      }
+      pc = op.skip;
+      continue;
+    }
+    // POP: op.b = pc of the matching PUSH, whose .b is the parent PUSH
+    uint32_t push_pc = op.b;
+    if (rec.any && rec.pc > push_pc) {  // the current closest hit was found inside this instance
+      if (code == OP_POP_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);  // translate.rs:18
+      else {                                                                              // transform.rs:152-161
+        const rl_transform &t = P.transforms[op.a];
+        rec.p = mat3_mul(t.m, rec.p);
+        D3 wn = mat3_mul(t.inv_t, rec.normal);
+        double m = len2(wn);
+        if (approx_eq_eps(m, 0.0, 1e-16)) gc.flagged++;  // "Instance normal couldn't be normalized"
+        else rec.normal = normalize(wn);
+      }
+    }
+    replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
+    ra = ray_aux(o, d);
+    pc++;
+  }
+}
+
 template <int NT, bool STATS>
 __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,93 +316,11 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
         Rec rec;
         rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false, rec.front = true;
         rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
-        D3 o = wo, d = wd;
-        RayAux ra = ray_aux(o, d);
-        uint32_t pc = 0;
-        for (;;) {
-          const DevOp &op = ops[pc];
-          uint32_t code = op.code & 0xFFu;
-          if (code == OP_END) break;
-          if (code == OP_BOX || code == OP_BOX_SPH || code == OP_BOX_PLANAR) {
-            if (STATS) c_nodes++;
-            double bx[6] = {op.box[0], op.box[1], op.box[2], op.box[3], op.box[4], op.box[5]};
-            bool certain;
-            bool hitb = aabb_fast(bx, ra, rec.t, certain);
-            if (!(certain && ra.fast_ok && (op.code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, rec.t);  // rare: the reference's divisions
-            if (!hitb) {
-              pc = op.skip;
-              continue;
-            }
-            if (code == OP_BOX) {
-              pc++;
-              continue;
-            }
-            uint32_t a = op.a, b = op.b;
-            if (code == OP_BOX_SPH) {
-              if (STATS) c_sph++;
-              uint32_t ai = a & SPH_INDEX;
-              if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
-              if (b != NONE) {
-                if (STATS) c_sph++;
-                uint32_t bi = b & SPH_INDEX;
-                if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec)) c_flag++;
-              }
-            } else {
-              if (STATS) c_pl++;
-              if (planar_hit_rec(P.planars[a], pc, o, d, rec)) c_flag++;
-              if (b != NONE) {
-                if (STATS) c_pl++;
-                if (planar_hit_rec(P.planars[b], pc, o, d, rec)) c_flag++;
-              }
-            }
-            pc = op.skip;
-            continue;
-          }
-          if (code == OP_SPHERE) {
-            if (STATS) c_sph++;
-            uint32_t a = op.a, ai = a & SPH_INDEX;
-            if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
-            pc++;
-            continue;
-          }
-          if (code == OP_PLANAR) {
-            if (STATS) c_pl++;
-            if (planar_hit_rec(P.planars[op.a], pc, o, d, rec)) c_flag++;
-            pc++;
-            continue;
-          }
-          if (code == OP_PUSH_TRANSLATE) {  // translate.rs:15
-            if (STATS) c_inst++;
-            o = o - ld3(P.translates[op.a].offset);
-            ra = ray_aux(o, d);
-            pc++;
-            continue;
-          }
-          if (code == OP_PUSH_TRANSFORM) {  // transform.rs:145-149
-            if (STATS) c_inst++;
-            const rl_transform &t = P.transforms[op.a];
-            D3 no = mat3_mul(t.inv, o), nd = mat3_mul(t.inv, d);
-            o = no, d = nd;
-            ra = ray_aux(o, d);
-            pc++;
-            continue;
-          }
-          // POP: op.b = pc of the matching PUSH, whose .b is the parent PUSH
-          uint32_t push_pc = op.b;
-          if (rec.any && rec.pc > push_pc) {  // the current closest hit was found inside this instance
-            if (code == OP_POP_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);  // translate.rs:18
-            else {                                                                              // transform.rs:152-161
-              const rl_transform &t = P.transforms[op.a];
-              rec.p = mat3_mul(t.m, rec.p);
-              D3 wn = mat3_mul(t.inv_t, rec.normal);
-              double m = len2(wn);
-              if (approx_eq_eps(m, 0.0, 1e-16)) c_flag++;  // "Instance normal couldn't be normalized"
-              else rec.normal = normalize(wn);
-            }
-          }
-          replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
-          ra = ray_aux(o, d);
-          pc++;
+        {
+          GenCounters gc{0, 0, 0, 0, 0};
+          auto draw = [&]() { return rc.gen_f64(rng); };
+          general_trace<STATS, true>(P, ops, 0u, NONE, wo, wd, wo, wd, time, 1e-10, rec, gc, draw);
+          c_nodes += gc.nodes, c_sph += gc.spheres, c_pl += gc.planars, c_inst += gc.instances, c_flag += gc.flagged;
         }
         if (!rec.any) {
           color = color + thr * background;
@@ -287,7 +338,10 @@ __global__ void __launch_bounds__(NT) rtiow_general_kernel(RtiowParams P) {
         uint32_t kind = m.kind;
         D3 normal = rec.normal, p = rec.p;
         D3 nd;
-        if (kind == RL_MAT_LAMBERTIAN) {
+        if (kind == RL_MAT_ISOTROPIC) {  // material.rs:201-214: Vec3::random_unit_vector, attenuation = texture.value(uv, p)
+          nd = rc.unit_sphere(rng);
+          thr = thr * texture_value<2>(P, m.texture, rec.u, rec.v, rec.p);
+        } else if (kind == RL_MAT_LAMBERTIAN) {
           D3 dir = normal + rc.unit_sphere(rng);
           bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
           nd = near_zero ? normal : dir;

@@ -24,6 +24,7 @@ struct RtiowParams {
   const DevImage *images;
   const float *image_pool;
   const rl_perlin *perlins;
+  const rl_medium *media;
   uint32_t n_ops, n_spheres;
   const DevMaterial *sphere_flat;  // wave kernel: per-sphere flattened material (see flatten_sphere_materials)
   const DevOp *lops;  // wave kernel: ops with {code, skip} replaced by linked successor words (state << 29 | op index), see link_ops

@@ -66,6 +66,7 @@ struct rl_scene {
   rl::DevImage *d_images = nullptr;
   float *d_image_pool = nullptr;
   rl_perlin *d_perlins = nullptr;
+  rl_medium *d_media = nullptr;
   // RTC
   rl::DevTri *d_tris = nullptr;
   rl_rtc_transformed *d_xforms = nullptr;

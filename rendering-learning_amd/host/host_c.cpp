@@ -184,7 +184,7 @@ int rlh_b_noise(rlh_builder *b, double scale, uint64_t seed) {
 int rlh_b_material(rlh_builder *b, uint32_t kind, int tex, const double *albedo, double fuzz, double ior) {
   auto m = std::make_shared<rtiow::Material>();
   m->kind = kind;
-  if (kind == RL_MAT_LAMBERTIAN || kind == RL_MAT_DIFFUSE_LIGHT) {
+  if (kind == RL_MAT_LAMBERTIAN || kind == RL_MAT_DIFFUSE_LIGHT || kind == RL_MAT_ISOTROPIC) {
     if (tex < 0 || (size_t)tex >= b->tex.size()) return -1;
     m->texture = b->tex[tex];
   }
@@ -229,6 +229,11 @@ int rlh_b_triangle(rlh_builder *b, const double *p9, const double *uv6_or_null, 
 int rlh_b_translate(rlh_builder *b, int obj, const double *off) {
   if (!oko(b, obj)) return -1;
   b->obj.push_back(std::make_shared<rtiow::Translate>(b->obj[obj], rtiow::Vec3(off[0], off[1], off[2])));
+  return (int)b->obj.size() - 1;
+}
+int rlh_b_medium(rlh_builder *b, int boundary, double density, int mat) {  // ConstantMedium::new (constant_medium.rs:16-24)
+  if (!oko(b, boundary) || !okm(b, mat)) return -1;
+  b->obj.push_back(std::make_shared<rtiow::ConstantMedium>(b->obj[boundary], density, b->mat[mat]));
   return (int)b->obj.size() - 1;
 }
 // op: 0 rotate_x, 1 rotate_y, 2 rotate_z (degrees), 3 uniform scale

@@ -228,6 +228,12 @@ inline MaterialPtr DiffuseLight(TexturePtr t) {
   m->texture = t;
   return m;
 }
+inline MaterialPtr Isotropic(TexturePtr t) {  // material.rs:197-199
+  auto m = std::make_shared<Material>();
+  m->kind = RL_MAT_ISOTROPIC;
+  m->texture = t;
+  return m;
+}
 
 // ---------------------------------------------------------------- flattener
 struct Flattened {
@@ -243,6 +249,7 @@ struct Flattened {
   std::vector<rl_image> images;
   std::vector<std::shared_ptr<ImageData>> image_keep;
   std::vector<rl_perlin> perlins;
+  std::vector<rl_medium> media;
   std::map<const Perlin *, uint32_t> perlin_ids;
   std::map<const Material *, uint32_t> mat_ids;
   std::map<const Texture *, uint32_t> tex_ids;
@@ -287,7 +294,7 @@ struct Flattened {
     if (it != mat_ids.end()) return it->second;
     rl_material r{};
     r.kind = m->kind;
-    if (m->kind == RL_MAT_LAMBERTIAN || m->kind == RL_MAT_DIFFUSE_LIGHT) r.texture = texture_id(m->texture);
+    if (m->kind == RL_MAT_LAMBERTIAN || m->kind == RL_MAT_DIFFUSE_LIGHT || m->kind == RL_MAT_ISOTROPIC) r.texture = texture_id(m->texture);
     r.albedo[0] = m->albedo.x(), r.albedo[1] = m->albedo.y(), r.albedo[2] = m->albedo.z();
     r.fuzz = m->fuzz;
     r.ior = m->ior;
@@ -309,6 +316,7 @@ struct Flattened {
     d.textures = textures.data(), d.n_textures = (uint32_t)textures.size();
     d.images = images.data(), d.n_images = (uint32_t)images.size();
     d.perlins = perlins.data(), d.n_perlins = (uint32_t)perlins.size();
+    d.media = media.data(), d.n_media = (uint32_t)media.size();
     d.root = root;
     return d;
   }
@@ -456,6 +464,22 @@ struct Translate : Hittable {  // translate.rs
     t.child = object->flatten(f);
     f.translates.push_back(t);
     return rl_href{RL_H_TRANSLATE, (uint32_t)f.translates.size() - 1};
+  }
+};
+
+struct ConstantMedium : Hittable {  // hittable/constant_medium.rs:9-25 (evaluated with the pixel's RNG: include/rl_render.h rl_medium)
+  HittablePtr boundary;
+  double neg_inv_density;
+  MaterialPtr phase_function;
+  ConstantMedium(HittablePtr b, double density, MaterialPtr m) : boundary(b), neg_inv_density(-1.0 / density), phase_function(m) {}
+  AABB bounding_box() const override { return boundary->bounding_box(); }  // constant_medium.rs:82-84
+  rl_href flatten(Flattened &f) const override {
+    rl_medium m{};
+    m.boundary = boundary->flatten(f);
+    m.neg_inv_density = neg_inv_density;
+    m.material = f.material_id(phase_function);
+    f.media.push_back(m);
+    return rl_href{RL_H_MEDIUM, (uint32_t)f.media.size() - 1};
   }
 };
 

@@ -1,0 +1,127 @@
+"""ConstantMedium (hittable/constant_medium.rs:9-80) + Isotropic (material.rs:197-219), deterministic variant: the free path is
+drawn from the pixel's ChaCha8 stream instead of the process-global rand::random (constant_medium.rs:55), see include/rl_render.h
+rl_medium.  CPU tier: the oracle against hand-computed draws and the Beer-Lambert law; GPU tier: device = oracle."""
+import math
+
+import numpy as np
+import pytest
+
+
+def _slab_world(rl, density, boundary="sphere"):
+    def scene(b):
+        fog = b.isotropic(b.solid((1.0, 1.0, 1.0)))
+        if boundary == "sphere":
+            shape = b.sphere((0, 0, -5), 1.0, b.flat())
+        else:  # an axis-aligned box of six quads, 2 x 2 x 2, centred at (0, 0, -5)
+            m = b.flat()
+            shape = b.list([b.quad((-1, -1, -4), (2, 0, 0), (0, 2, 0), m), b.quad((-1, -1, -6), (2, 0, 0), (0, 2, 0), m),
+                            b.quad((-1, -1, -6), (0, 0, 2), (0, 2, 0), m), b.quad((1, -1, -6), (0, 0, 2), (0, 2, 0), m),
+                            b.quad((-1, -1, -6), (2, 0, 0), (0, 0, 2), m), b.quad((-1, 1, -6), (2, 0, 0), (0, 0, 2), m)])
+        return b.list([b.constant_medium(shape, density, fog)])
+    return rl.World.build(scene)
+
+
+def test_oracle_medium_first_draw_by_hand(rl, oracle):
+    """depth 1: a scattered ray contributes 0, a miss the background.  Per sample the draws are px, py, time (camera.rs:203-216), then the
+    medium's free path -(1/density) * ln(gen::<f64>()) — the fourth f64 of the pixel's stream for sample 0."""
+    density = 0.4
+    world = _slab_world(rl, density)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=9, samples_per_pixel=1, max_depth=1, vfov=10.0, lookfrom=(0, 0, 0), lookat=(0, 0, -5),
+                        background=(0.25, 0.5, 0.75), seed=3)
+    cam = rl.Camera(p)
+    img = oracle.rtiow_render(world.desc, cam.c)
+    W = H = 9
+    x = y = 4  # the centre pixel looks through ~2 units of fog (a little less off-axis: recompute the chord from the actual ray)
+    ops = [("set_stream", 0 * W * H + x * W + y), ("f64",), ("f64",), ("f64",), ("f64",)]
+    out, _ = oracle.chacha_script(p.seed, ops)
+    px, py, _time, u = out[1], out[2], out[3], out[4]
+    c = cam.c
+    centre = np.array(c.pixel_00) + np.array(c.pixel_du) * x + np.array(c.pixel_dv) * y
+    sample = centre + np.array(c.pixel_du) * (-0.5 + px) + np.array(c.pixel_dv) * (-0.5 + py)
+    d = sample - np.array(c.lookfrom)
+    oc = np.array(c.lookfrom) - np.array([0.0, 0.0, -5.0])
+    a, hb, cc = d @ d, oc @ d, oc @ oc - 1.0
+    sq = math.sqrt(hb * hb - a * cc)
+    inside = ((-hb + sq) / a - (-hb - sq) / a) * math.sqrt(a)
+    hit_distance = -(1.0 / density) * math.log(u)
+    want = np.zeros(3) if hit_distance <= inside else np.array(p.background)
+    assert np.array_equal(img[y, x], want)
+    corner = img[0, 0]  # misses the sphere: no draw, background
+    assert np.array_equal(corner, np.array(p.background))
+
+
+@pytest.mark.parametrize("boundary", ["sphere", "box"])
+def test_oracle_medium_obeys_beer_lambert(rl, oracle, boundary):
+    density = 0.35
+    world = _slab_world(rl, density, boundary)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=3, samples_per_pixel=20000, max_depth=1, vfov=0.5, lookfrom=(0, 0, 0), lookat=(0, 0, -5),
+                        background=(1.0, 1.0, 1.0), seed=11)
+    cam = rl.Camera(p)
+    img = oracle.rtiow_render(world.desc, cam.c) / p.samples_per_pixel
+    want = math.exp(-density * 2.0)  # a 2-unit chord along the axis (vfov 0.5 degrees: every ray is practically axial)
+    sigma = math.sqrt(want * (1 - want) / p.samples_per_pixel)
+    assert abs(img[1, 1, 0] - want) < 5 * sigma
+    again = oracle.rtiow_render(world.desc, cam.c) / p.samples_per_pixel  # deterministic: same seed, same image
+    assert np.array_equal(img, again)
+    other = oracle.rtiow_render(world.desc, rl.Camera(rl.CameraParams(**{**p.__dict__, "seed": 12})).c) / p.samples_per_pixel
+    assert not np.array_equal(img, other)
+
+
+def _smoke_scene(b):
+    """examples/cornell_smoke.rs in miniature: a room of quads, a light, two rotated / translated boxes of smoke, plus final_scene.rs's
+    glass ball with a medium inside."""
+    white = b.lambertian(b.solid((0.73, 0.73, 0.73)))
+    green = b.lambertian(b.solid((0.12, 0.45, 0.15)))
+    red = b.lambertian(b.solid((0.65, 0.05, 0.05)))
+    light = b.diffuse_light(b.solid((7, 7, 7)))
+
+    def box(lo, hi, m):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        dx, dy, dz = (x1 - x0, 0, 0), (0, y1 - y0, 0), (0, 0, z1 - z0)
+        return b.list([b.quad((x0, y0, z1), dx, dy, m), b.quad((x1, y0, z1), (0, 0, -(z1 - z0)), dy, m), b.quad((x1, y0, z0), (-(x1 - x0), 0, 0), dy, m),
+                       b.quad((x0, y0, z0), dz, dy, m), b.quad((x0, y1, z1), dx, (0, 0, -(z1 - z0)), m), b.quad((x0, y0, z0), dx, dz, m)])
+    room = [b.quad((555, 0, 0), (0, 555, 0), (0, 0, 555), green), b.quad((0, 0, 0), (0, 555, 0), (0, 0, 555), red),
+            b.quad((113, 554, 127), (330, 0, 0), (0, 0, 305), light), b.quad((0, 555, 0), (555, 0, 0), (0, 0, 555), white),
+            b.quad((0, 0, 0), (555, 0, 0), (0, 0, 555), white), b.quad((0, 0, 555), (555, 0, 0), (0, 555, 0), white)]
+    box1 = b.translate(b.rotate_y(box((0, 0, 0), (165, 330, 165), white), 15.0), (265, 0, 295))
+    box2 = b.translate(b.rotate_y(box((0, 0, 0), (165, 165, 165), white), -18.0), (130, 0, 65))
+    smoke1 = b.constant_medium(box1, 0.01, b.isotropic(b.solid((0, 0, 0))))
+    smoke2 = b.constant_medium(box2, 0.01, b.isotropic(b.solid((1, 1, 1))))
+    ball = b.sphere((400, 90, 120), 60, b.dielectric(1.5))
+    haze = b.constant_medium(b.sphere((400, 90, 120), 60, b.dielectric(1.5)), 0.2, b.isotropic(b.solid((0.2, 0.4, 0.9))))
+    return b.bvh(room + [smoke1, smoke2, ball, haze])
+
+
+@pytest.mark.gpu
+def test_gpu_constant_medium_equals_oracle(rl, oracle):
+    import torch
+    world = rl.World.build(_smoke_scene)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=72, samples_per_pixel=24, max_depth=30, vfov=40.0, lookfrom=(278, 278, -800), lookat=(278, 278, 0),
+                        background=(0, 0, 0), seed=5)
+    cam = rl.Camera(p)
+    gs, cs = {}, {}
+    gpu = cam.render(world, stats=gs).data
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    # colours: log() is the device libm here and glibc in the oracle (<= 2 ulp apart); it feeds the scatter POINT, i.e. colour-level noise
+    assert np.abs(gpu - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
+    buf = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+    cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    st = rl.api.render_status(world)
+    assert np.array_equal(buf.cpu().numpy(), gpu) and st["rays"] == gs["rays"] and st["slow_traces"] == 0
+    assert cam.render(world).data.tobytes() == gpu.tobytes()  # deterministic
+
+
+@pytest.mark.gpu
+def test_gpu_medium_row_shards_and_first_sample(rl, oracle):
+    world = _slab_world(rl, 0.4, "box")
+    p = rl.CameraParams(aspect_ratio=1.5, image_width=48, samples_per_pixel=9, max_depth=8, vfov=35.0, lookfrom=(0.5, 0.4, 0), lookat=(0, 0, -5),
+                        background=(0.7, 0.8, 1.0), seed=2)
+    cam = rl.Camera(p)
+    full = cam.render(world).data
+    for g, G in ((0, 2), (1, 2), (2, 5)):
+        assert np.array_equal(cam.render_rows(world, g, G), full[g::G])
+    part = cam.render_rows(world, 0, 1, first_sample=9)
+    cpu = oracle.rtiow_render(world.desc, cam.c, first_sample=9)
+    assert np.abs(part - cpu).max() <= 1e-9

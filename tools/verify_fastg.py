@@ -8,8 +8,11 @@ from PIL import Image
 rl.init(0)
 G = os.path.join(ROOT, "tests", "golden")
 tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB")); obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
-w = rl.World.stress_scene(1000, 2, obj, tex)
-p = w.params; p.samples_per_pixel = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+if len(sys.argv) > 2 and sys.argv[2] == "cow":
+    w = rl.World.cow_scene(obj, tex); p = w.params; p.aspect_ratio, p.image_width = 16.0 / 9.0, 3840
+else:
+    w = rl.World.stress_scene(1000, 2, obj, tex); p = w.params
+p.samples_per_pixel = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 cam = rl.Camera(p)
 buf = torch.zeros((cam.c.image_height, cam.c.image_width, 3), dtype=torch.float64, device="cuda:0")
 cam.render_device(w, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
@@ -18,6 +21,8 @@ L = rl.api.render_lib()
 cnt = C.c_uint32(); log = (C.c_double * 768)()
 L.rl_debug_fastg_verify(C.byref(cnt), log)
 print("rays", st["rays"], "mismatching rays", cnt.value)
+c4 = (C.c_uint64 * 4)(); L.rl_debug_fastg_counts(c4)
+print("per ray: TRAV steps %.2f  LEAF visits %.2f  far-origin rays %.4f" % (c4[0] / st["rays"], c4[1] / st["rays"], c4[2] / st["rays"]))
 a = np.array(log).reshape(64, 12)
 np.set_printoptions(precision=17, linewidth=250)
 for r in a[:min(cnt.value, 8)]:
