@@ -172,6 +172,38 @@ def test_degenerate_sphere_scenes_do_not_use_the_fast_structure(rl, oracle):
     assert _same_bits(fast, ref_order) and _same_bits(fast, counting) and gs["flagged"] > 100
 
 
+@pytest.mark.parametrize("scene", ["horizon", "far_camera"])
+def test_guarded_and_unguarded_ops_render_the_same_bits(rl, scene):
+    """The counting kernel's guard ops (variant 1027: a sphere's own padded box may skip its Sphere::hit) against the same kernel without
+    them (1025), on rays that graze spheres and on origins far from tiny spheres — where a wrong reject would show."""
+    api = rl.api
+    tex, mats = _mats(api)
+    if scene == "horizon":
+        sph = np.zeros(4, dtype=api.SPHERE)
+        sph["center0"] = [(0, -1000, 0), (0, 0.5, -30), (3, 0.2, -20), (-4, 1.0, -40)]
+        sph["radius"] = [1000.0, 0.5, 0.2, 1.0]
+        sph["material"] = [4, 3, 2, 0]
+        p = rl.CameraParams(aspect_ratio=4.0, image_width=256, samples_per_pixel=8, max_depth=10, vfov=3.0, lookfrom=(0, 0.02, 10), lookat=(0, -0.45, -90), seed=5)
+    else:  # 0.01-radius spheres seen from 400 units: |oc| / r = 4e4
+        rng = np.random.default_rng(3)
+        sph = np.zeros(60, dtype=api.SPHERE)
+        sph["center0"], sph["radius"], sph["material"] = rng.uniform(-0.5, 0.5, (60, 3)), 0.01, rng.integers(0, 5, 60)
+        p = rl.CameraParams(aspect_ratio=1.0, image_width=128, samples_per_pixel=8, max_depth=6, vfov=0.2, lookfrom=(0, 0, 400.0), lookat=(0, 0, 0), seed=6)
+    world = rl.World.from_spheres(sph, mats, tex, True)
+    cam = rl.Camera(p)
+    frames = {}
+    try:
+        for v in (1027, 1025):
+            api.set_rtiow_variant(v)
+            st = {}
+            frames[v] = (cam.render(world, stats=st).data, st)
+    finally:
+        api.set_rtiow_variant(0)
+    assert _same_bits(frames[1027][0], frames[1025][0])
+    for k in ("rays", "node_tests", "sphere_tests", "rng_words", "flagged"):
+        assert frames[1027][1][k] == frames[1025][1][k], k
+
+
 def test_grazing_rays_over_a_sphere_horizon(rl, oracle):
     """A camera sitting on a huge sphere looking along its surface: most primary rays graze the ground sphere or pass just above it."""
     api = rl.api
