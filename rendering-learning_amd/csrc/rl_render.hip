@@ -779,6 +779,17 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
+    if (variant == 1029) {
+      // latency mode (A/B only, RL_THIN=<permille of the tiles>, default off): the most expensive tiles are rendered 16 pixels per wave.
+      // Measured on the emulated 1/8 shard: 281 -> 271 ms at 3 %, nothing at 6-12 %, slower beyond and on the 1/4 shard: the longest
+      // sample chain's time is per-ray LATENCY (a lone ray needs ~6 us: dependent LDS / L2 round trips and binary64 sqrt / div chains),
+      // which thinner waves do not shorten
+      double permille = 0.0;
+      if (const char *e = std::getenv("RL_THIN")) permille = std::atof(e);
+      P.thin_tiles = (uint32_t)((double)ntiles * permille / 1000.0);
+      uint64_t total = slots + (uint64_t)P.thin_tiles * 192u;
+      if (total >= 0xFFFF0000ull) P.thin_tiles = 0;
+    }
     rc = launch_variant();
   }
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));

@@ -28,7 +28,7 @@ namespace rl {
 
 // ST_SHADE2 (fast traversal only): the specular half of SHADE — Metal and Dielectric hits — so that the many Lambertian / miss lanes
 // do not walk through normalize(), Schlick and refract() code they never need
-enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6 };
+enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6, ST_PARK = 7 };
 
 // two-block ChaCha ring in LDS: 16 u64 slots per lane, slot-major ([slot][lane]) => conflict-free
 template <int NT>
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   uint32_t state = ST_GEN;
   uint32_t px = 0, pr = 0, n = spp;  // n == spp: no pixel owned yet
   uint32_t ptile = 0, pix_rays = 0;
-  bool have_pixel = false;
+  bool have_pixel = false, thin_pix = false;
   D3 sum = d3(0.0, 0.0, 0.0);
   D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), thr = d3(1.0, 1.0, 1.0);
   RayAux ra = ray_aux(o, d);
@@ -561,6 +561,12 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     int n_gen = __popcll(__ballot(state == ST_GEN));
     int n_leaf = __popcll(__ballot(state == ST_LEAF));
     int n_shade2 = SPLIT_SHADE && LDS_SCENE == 4 ? __popcll(__ballot(state == ST_SHADE2)) : 0;
+    if (LDS_SCENE == 4 && P.thin_tiles != 0u) {  // parked lanes wake up when no lane of the wave holds a thin pixel any more
+      if (__ballot(state == ST_PARK) != 0ull && __ballot(have_pixel && thin_pix) == 0ull) {
+        if (state == ST_PARK) state = ST_GEN;
+        n_gen = __popcll(__ballot(state == ST_GEN));
+      }
+    }
     if ((n_trav | n_shade | n_fill | n_gen | n_leaf | n_shade2) == 0) break;
     uint32_t pick = ST_TRAV;
     int best = n_trav;
@@ -708,7 +714,23 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             have_pixel = false;
           }
           uint32_t slot = wave_claim(P.work_counter);
-          if (slot >= P.n_slots) {
+          // THIN tiles (latency mode, LDS_SCENE = 4, cost-sorted resume launch of a small shard): the P.thin_tiles most expensive tiles
+          // hand out their 64 pixels over FOUR wave-claims of 64 slots, 16 pixels each; a lane that draws one of the 48 empty slots
+          // parks until its wave's thin pixels are done.  A wave then serialises 16 sample chains instead of 64: the longest chains
+          // of the frame (the shard's critical path) see a quarter of the state divergence.
+          const uint32_t thin_slots = LDS_SCENE == 4 ? P.thin_tiles * 256u : 0u;
+          thin_pix = false;
+          bool parked = false;
+          if (slot < thin_slots) {
+            const uint32_t sub = slot & 255u, l = sub & 63u;
+            parked = (l & 3u) != 0u;
+            thin_pix = !parked;
+            slot = (slot >> 8) * 64u + (sub >> 6) * 16u + (l >> 2);
+          } else slot -= thin_slots - P.thin_tiles * 64u;
+          if (parked) {
+            state = ST_PARK;
+            active = false;
+          } else if (slot >= P.n_slots) {
             state = ST_DONE;
             active = false;
           } else {
