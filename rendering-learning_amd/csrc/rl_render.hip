@@ -780,14 +780,17 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
     if (variant == 1029) {
-      // latency mode (A/B only, RL_THIN=<permille of the tiles>, default off): the most expensive tiles are rendered 16 pixels per wave.
-      // Measured on the emulated 1/8 shard: 281 -> 271 ms at 3 %, nothing at 6-12 %, slower beyond and on the 1/4 shard: the longest
-      // sample chain's time is per-ray LATENCY (a lone ray needs ~6 us: dependent LDS / L2 round trips and binary64 sqrt / div chains),
-      // which thinner waves do not shorten
+      // latency modes (A/B only, default off): RL_THIN=<permille of the tiles> renders the most expensive tiles
+      // 64 >> RL_THIN_SHIFT pixels per wave, RL_PRIO=<permille> raises the issue priority of the waves that hold them.  Measured on the
+      // emulated 1/8 shard: 271 - 283 ms against 279 at best, slower when more than ~1 % of the tiles are thinned: the longest sample
+      // chain's time is per-ray LATENCY (9.6 us for a pixel alone on the GPU, tools/lone_ray.py), which neither shortens
       double permille = 0.0;
       if (const char *e = std::getenv("RL_THIN")) permille = std::atof(e);
       P.thin_tiles = (uint32_t)((double)ntiles * permille / 1000.0);
-      uint64_t total = slots + (uint64_t)P.thin_tiles * 192u;
+      P.thin_shift = 2;
+      if (const char *e = std::getenv("RL_PRIO")) P.prio_tiles = (uint32_t)((double)ntiles * std::atof(e) / 1000.0);  // A/B
+      if (const char *e = std::getenv("RL_THIN_SHIFT")) P.thin_shift = (uint32_t)std::min(6, std::max(1, std::atoi(e)));
+      uint64_t total = slots + (((uint64_t)P.thin_tiles * 64u) << P.thin_shift);
       if (total >= 0xFFFF0000ull) P.thin_tiles = 0;
     }
     rc = launch_variant();
@@ -1102,12 +1105,19 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
   uint64_t want = (total + NT - 1) / NT;
   uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
-  if (rc_.needs_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
+  static const bool force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;  // A/B: triangle-only worlds through the full kernel
+  if (rc_.needs_full || force_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
     RtcFullParams F{};
     F.R = P;
     F.shapes = scene->d_shapes, F.csgs = scene->d_csgs, F.patterns = scene->d_patterns;
     F.n_tris = P.n_tris, F.max_reflection_depth = rc_.max_reflection_depth;
-    hipLaunchKernelGGL((rtc_full_kernel<NT>), dim3(blocks), dim3(NT), 0, stream, F);
+    // register budget of three waves per SIMD (168 VGPRs; ~165 of the kernel's binary64 temporaries then live in scratch, at points that
+    // run once per ray): measured 13.3 / 14.0 / 19.2 ms for 3 / 2 / 1 waves on the mirror scene at 1080p, 2.7 / 2.9 / 4.2 ms on the teapot
+    // forced through this kernel.  RL_RTC_FULL_REGS=256|512 selects the other budgets (A/B).
+    static const int regs_for = std::getenv("RL_RTC_FULL_REGS") ? std::atoi(std::getenv("RL_RTC_FULL_REGS")) : 768;
+    if (regs_for == 512) hipLaunchKernelGGL((rtc_full_kernel<NT, 512>), dim3(blocks), dim3(NT), 0, stream, F);
+    else if (regs_for == 256) hipLaunchKernelGGL((rtc_full_kernel<NT, 256>), dim3(blocks), dim3(NT), 0, stream, F);
+    else hipLaunchKernelGGL((rtc_full_kernel<NT, 768>), dim3(blocks), dim3(NT), 0, stream, F);
   } else if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
   else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
   HIP_TRY(hipGetLastError());

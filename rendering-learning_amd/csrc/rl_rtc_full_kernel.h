@@ -6,7 +6,9 @@
 // One lane per pixel.  A ray's intersections are collected into a per-lane list (scratch memory) in the
 // reference's evaluation order; CSG scopes sort + filter their own range (csg.rs:50-108), Transformed scopes
 // re-normalise the normals of theirs (transformed.rs:43-49); the world-level stable sort by t then gives exactly
-// the reference's `xs`.  The reflection / refraction tree is walked with an explicit stack of weighted rays:
+// the reference's `xs`.  An entry is 40 bytes {t, leaf, enclosing ENTER, normal}: the surface colour (material.rs:13-20, a pure
+// function of the local-space point) is evaluated for the HIT only, from the local ray its ENTER chain reproduces, and neither the
+// containers walk nor the shadow test keeps a list of its own (both are answered by rescanning the sorted entries).  The reflection / refraction tree is walked with an explicit stack of weighted rays:
 // colour is linear in the sub-rays' colours (reflectivity, transparency and the Schlick factor are scalars), so
 // total = sum over tree nodes of weight * surface colour — a reassociation of the reference's sums (ulp-level).
 #pragma once
@@ -27,10 +29,11 @@ struct RtcFullParams {
 
 struct Ent {  // one Intersection (intersect.rs:11-16) + the CSG side tag
   double t;
-  uint32_t leaf;  // triangles first, then shapes: object identity
-  uint32_t right;
-  D3 normal, color;
+  uint32_t leaf;   // triangles first, then shapes: object identity; bit 31: CSG side tag (set = right child)
+  uint32_t chain;  // pc of the innermost enclosing ROP_ENTER (NONE: world space): reproduces the local ray for the hit's colour
+  D3 normal;
 };
+static const uint32_t ENT_RIGHT = 0x80000000u;
 
 __device__ __forceinline__ long long f2i64(double f) { return (long long)f; }  // v_cvt saturates; NaN -> 0
 
@@ -57,10 +60,10 @@ struct RtcFullCounters {
   unsigned long long rays, nodes, tris, spheres, enters, flagged;
 };
 
-__device__ __forceinline__ void ent_push(Ent *list, uint32_t &n, double t, uint32_t leaf, D3 normal, D3 color, RtcFullCounters &cnt) {
+__device__ __forceinline__ void ent_push(Ent *list, uint32_t &n, double t, uint32_t leaf, uint32_t chain, D3 normal, RtcFullCounters &cnt) {
   if (n < RL_RTC_K) {
     Ent e;
-    e.t = t, e.leaf = leaf, e.right = 0, e.normal = normal, e.color = color;
+    e.t = t, e.leaf = leaf, e.chain = chain, e.normal = normal;
     list[n++] = e;
   } else
     cnt.flagged++;
@@ -85,6 +88,22 @@ __device__ inline void ent_sort(Ent *list, uint32_t lo, uint32_t hi) {  // stabl
   }
 }
 
+// The ray inside the Transformed scope whose ROP_ENTER is at `chain` (NONE: the world ray): transformed.rs:38-41 applied outermost first
+__device__ inline void rtc_local_ray(const RtcParams &P, const DevOp *ops, uint32_t chain, D3 wo, D3 wd, D3 &o, D3 &d) {
+  o = wo, d = wd;
+  uint32_t stack[8];
+  int ns = 0;
+  while (chain != NONE && ns < 8) {
+    stack[ns++] = chain;
+    chain = ops[chain].b;
+  }
+  for (int i = ns - 1; i >= 0; i--) {
+    const rl_rtc_transformed &px = P.xforms[ops[stack[i]].a];
+    D3 no = mul_point(px.inverse, o), nd = mul_vec(px.inverse, d);
+    o = no, d = nd;
+  }
+}
+
 // World::intersect (world.rs:46-55) into list[0..n): evaluation order, CSG-filtered, normals in world space, sorted by t
 __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp *ops, const DevTri *tris, D3 wo, D3 wd, Ent *list,
                                             RtcFullCounters &cnt, unsigned long long mult) {
@@ -93,6 +112,7 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
   uint32_t n = 0, pc = 0;
   uint32_t xf_start[8], csg_start[4], csg_mid[4];
   int xf_depth = 0, csg_depth = 0;
+  uint32_t cur_enter = NONE;  // innermost enclosing ROP_ENTER
   for (;;) {
     const DevOp &op = ops[pc];
     uint32_t code = op.code;
@@ -115,14 +135,13 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
         if (v < 0.0 || (u + v) > 1.0) continue;
         double tt = f * dot(e2, origin_cross_e1);
         D3 nn = t.smooth ? nrm_or_flag((ld3(t.n2) * u + ld3(t.n3) * v) + ld3(t.n1) * (1.0 - u - v), cnt) : ld3(t.n1);
-        ent_push(list, n, tt, first + k, nn, rtc_surface_color(F, P.materials[t.material], o + d * tt), cnt);
+        ent_push(list, n, tt, first + k, cur_enter, nn, cnt);
       }
       pc++;
       continue;
     }
     if (code == ROP_SHAPE) {
       const rl_rtc_shape &sh = F.shapes[op.a];
-      const rl_rtc_material &m = P.materials[sh.material];
       uint32_t leaf = F.n_tris + op.a;
       const double EPS = 1e-8;
       double ts[4];
@@ -218,7 +237,7 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
             nn = nrm_or_flag(d3(p.x, y, p.z), cnt);
           }
         }
-        ent_push(list, n, t, leaf, nn, rtc_surface_color(F, m, p), cnt);
+        ent_push(list, n, t, leaf, cur_enter, nn, cnt);
       }
       pc++;
       continue;
@@ -247,6 +266,7 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
       o = no, d = nd;
       if (xf_depth < 8) xf_start[xf_depth] = n;
       xf_depth++;
+      cur_enter = pc;
       pc++;
       continue;
     }
@@ -262,18 +282,8 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
         }
         list[i].normal = nn;
       }
-      o = wo, d = wd;  // parent ray: replay the enclosing ENTER chain from the world ray
-      uint32_t chain = op.b, stack[8];
-      int ns = 0;
-      while (chain != NONE && ns < 8) {
-        stack[ns++] = chain;
-        chain = ops[chain].b;
-      }
-      for (int i = ns - 1; i >= 0; i--) {
-        const rl_rtc_transformed &px = P.xforms[ops[stack[i]].a];
-        D3 no = mul_point(px.inverse, o), nd = mul_vec(px.inverse, d);
-        o = no, d = nd;
-      }
+      cur_enter = op.b;
+      rtc_local_ray(P, ops, cur_enter, wo, wd, o, d);  // parent ray: replay the enclosing ENTER chain from the world ray
       pc++;
       continue;
     }
@@ -291,13 +301,13 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
     {  // ROP_CSG_END: csg.rs:78-108 — left + right intersections, stable sort by t, filter by the operation
       csg_depth--;
       uint32_t start = csg_depth < 4 ? csg_start[csg_depth] : n, mid = csg_depth < 4 ? csg_mid[csg_depth] : n;
-      for (uint32_t i = start; i < n; i++) list[i].right = i >= mid ? 1u : 0u;
+      for (uint32_t i = start; i < n; i++) list[i].leaf = (list[i].leaf & ~ENT_RIGHT) | (i >= mid ? ENT_RIGHT : 0u);
       ent_sort(list, start, n);
       uint32_t operation = F.csgs[op.a].operation;
       bool in_l = false, in_r = false;
       uint32_t w = start;
       for (uint32_t i = start; i < n; i++) {
-        bool left = list[i].right == 0;
+        bool left = (list[i].leaf & ENT_RIGHT) == 0;
         bool allowed;
         if (operation == RL_CSG_UNION) allowed = (left && !in_r) || (!left && !in_l);
         else if (operation == RL_CSG_INTERSECTION) allowed = (left && in_r) || (!left && in_l);
@@ -314,8 +324,32 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
       continue;
     }
   }
+  for (uint32_t i = 0; i < n; i++) list[i].leaf &= ~ENT_RIGHT;
   ent_sort(list, 0, n);  // intersect::sort at world level (stable)
   return n;
+}
+
+// Material::color_at for the hit (material.rs:13-20): the local-space point is o' + d' * t with (o', d') the ray inside the hit's
+// innermost Transformed — the same sequence of products that produced it while intersecting, hence the same bits.
+__device__ inline D3 rtc_hit_color(const RtcFullParams &F, const DevOp *ops, const rl_rtc_material &m, uint32_t chain, double t, D3 wo, D3 wd) {
+  if (m.pattern == 0) return ld3(m.color);
+  D3 o, d;
+  rtc_local_ray(F.R, ops, chain, wo, wd, o, d);
+  return rtc_surface_color(F, m, o + d * t);
+}
+
+// containers.last() after the containers walk of intersect.rs:72-99 has processed list[0 .. upto): an object is in `containers` iff it
+// occurs an odd number of times in that prefix (second occurrence removes, third appends again ...), and the Vec's order is the order of
+// the objects' most recent append = their LAST occurrence.  NONE: empty.
+__device__ inline uint32_t rtc_last_container(const Ent *list, uint32_t upto) {
+  for (uint32_t j = upto; j-- > 0;) {
+    uint32_t leaf = list[j].leaf, count = 0;
+    bool later = false;
+    for (uint32_t k = 0; k < upto; k++)
+      if (list[k].leaf == leaf) count++, later |= k > j;
+    if (!later && (count & 1u)) return leaf;
+  }
+  return NONE;
 }
 
 __device__ __forceinline__ bool rtc_are_equal(double a, double b) {  // math/util.rs:4-22
@@ -338,8 +372,9 @@ struct Pending {
   unsigned long long mult;  // how many times the reference evaluates this ray (it recomputes reflected / refracted per light)
 };
 
-template <int NT>
-__global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
+// NT threads per workgroup; REGS_FOR = the workgroup size the register budget is computed for (512 -> 256 registers, two waves per SIMD)
+template <int NT, int REGS_FOR>
+__global__ void __launch_bounds__(REGS_FOR) rtc_full_kernel(RtcFullParams F) {
   const RtcParams &P = F.R;
   const int tid = threadIdx.x;
   const DevOp *ops = P.ops;
@@ -400,31 +435,17 @@ __global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
             reflect_v = cur.d;
           }
           double n1 = 1.0, n2 = 1.0;
-          {
-            uint32_t cont[RL_RTC_K];
-            uint32_t nc = 0;
-            for (uint32_t i = 0; i < n; i++) {
-              bool same = rtc_are_equal(list[i].t, h.t) && list[i].leaf == h.leaf;
-              if (same) n1 = nc ? P.materials[rtc_leaf_material(F, tris, cont[nc - 1])].refractive_index : 1.0;
-              uint32_t pos = nc;
-              for (uint32_t k = 0; k < nc; k++)
-                if (cont[k] == list[i].leaf) {
-                  pos = k;
-                  break;
-                }
-              if (pos < nc) {
-                for (uint32_t k = pos; k + 1 < nc; k++) cont[k] = cont[k + 1];
-                nc--;
-              } else
-                cont[nc++] = list[i].leaf;
-              if (same) {
-                n2 = nc ? P.materials[rtc_leaf_material(F, tris, cont[nc - 1])].refractive_index : 1.0;
-                break;
-              }
+          if (m.transparency != 0.0) {  // n1 / n2 feed only refracted_color and schlick, both of which need a transparent material
+            uint32_t is = 0;
+            while (is < n && !(rtc_are_equal(list[is].t, h.t) && list[is].leaf == h.leaf)) is++;
+            if (is < n) {
+              uint32_t c1 = rtc_last_container(list, is), c2 = rtc_last_container(list, is + 1);
+              if (c1 != NONE) n1 = P.materials[rtc_leaf_material(F, tris, c1)].refractive_index;
+              if (c2 != NONE) n2 = P.materials[rtc_leaf_material(F, tris, c2)].refractive_index;
             }
           }
           // shade_hit (world.rs:57-87); the list is reused for the shadow rays from here on
-          D3 object_color = h.color;
+          D3 object_color = rtc_hit_color(F, ops, m, h.chain, h.t, cur.o, cur.d);
           D3 lsum = d3(0.0, 0.0, 0.0);
           for (uint32_t li = 0; li < P.n_lights; li++) {
             const rl_rtc_light &light = P.lights[li];
@@ -436,14 +457,11 @@ __global__ void __launch_bounds__(NT) rtc_full_kernel(RtcFullParams F) {
             if (norm(v, sdir)) {
               cnt.rays += cur.mult;
               uint32_t ns = rtc_intersect_all(F, ops, tris, over_point, sdir, list, cnt, cur.mult);
-              uint32_t seen[RL_RTC_K];
-              uint32_t nseen = 0;
               for (uint32_t i = 0; i < ns; i++) {
                 if (!(list[i].t > 0.0 && list[i].t < distance)) continue;
-                bool dup = false;
-                for (uint32_t k = 0; k < nseen; k++) dup |= seen[k] == list[i].leaf;
-                if (dup) break;  // take_while(seen.insert)
-                seen[nseen++] = list[i].leaf;
+                bool dup = false;  // take_while(seen.insert): every earlier in-range entry is in `seen`
+                for (uint32_t k = 0; k < i; k++) dup |= list[k].t > 0.0 && list[k].t < distance && list[k].leaf == list[i].leaf;
+                if (dup) break;
                 shadow_att = shadow_att * P.materials[rtc_leaf_material(F, tris, list[i].leaf)].transparency;
               }
             }

@@ -52,7 +52,9 @@ struct RtiowParams {
   uint32_t *tile_cost;                         // per-tile ray count accumulated at pixel end, or null
   double k8u;                 // 8 * 2^-53, passed as a kernel argument so it lives in SGPRs (one v_fma instead of v_mov + v_fmac with a literal)
   uint32_t tune[4];           // wave kernel: [0] max TRAV steps per scheduling round, [1] leave-TRAV population floor in 1/16ths
-  uint32_t thin_tiles;        // fast wave kernel, resume launch: the first thin_tiles tiles of tile_order are handed out 16 pixels per wave
+  uint32_t thin_tiles;        // fast wave kernel, resume launch: the first thin_tiles tiles of tile_order are handed out 64 >> thin_shift pixels per wave
+  uint32_t thin_shift;        // 2 (16 pixels per wave) .. 6 (one pixel per wave)
+  uint32_t prio_tiles;        // fast wave kernel, resume launch (A/B): a wave holding a pixel of the first prio_tiles tiles runs at s_setprio 3
   uint32_t *pix_rays;         // debug (tools/): per-pixel ray counts, accumulated at pixel end by the counting wave kernel, or null
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
 };

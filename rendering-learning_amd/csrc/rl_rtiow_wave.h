@@ -715,18 +715,22 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           }
           uint32_t slot = wave_claim(P.work_counter);
           // THIN tiles (latency mode, LDS_SCENE = 4, cost-sorted resume launch of a small shard): the P.thin_tiles most expensive tiles
-          // hand out their 64 pixels over FOUR wave-claims of 64 slots, 16 pixels each; a lane that draws one of the 48 empty slots
+          // hand out their 64 pixels over 1 << thin_shift wave-claims of 64 slots (16 … 1 pixels each); a lane that draws an empty slot
           // parks until its wave's thin pixels are done.  A wave then serialises 16 sample chains instead of 64: the longest chains
           // of the frame (the shard's critical path) see a quarter of the state divergence.
-          const uint32_t thin_slots = LDS_SCENE == 4 ? P.thin_tiles * 256u : 0u;
+          const uint32_t sh = P.thin_shift;  // a thin tile's 64 pixels go out over 1 << sh wave-claims, 64 >> sh pixels each
+          const uint32_t thin_slots = LDS_SCENE == 4 ? (P.thin_tiles * 64u) << sh : 0u;
           thin_pix = false;
           bool parked = false;
           if (slot < thin_slots) {
-            const uint32_t sub = slot & 255u, l = sub & 63u;
-            parked = (l & 3u) != 0u;
+            const uint32_t sub = slot & ((64u << sh) - 1u), l = sub & 63u;
+            parked = (l & ((1u << sh) - 1u)) != 0u;
             thin_pix = !parked;
-            slot = (slot >> 8) * 64u + (sub >> 6) * 16u + (l >> 2);
-          } else slot -= thin_slots - P.thin_tiles * 64u;
+            slot = (slot >> (6u + sh)) * 64u + (sub >> 6) * (64u >> sh) + (l >> sh);
+          } else {
+            slot -= thin_slots - P.thin_tiles * 64u;
+            if (LDS_SCENE == 4 && P.prio_tiles != 0u) thin_pix = (slot >> 6) < P.prio_tiles;
+          }
           if (parked) {
             state = ST_PARK;
             active = false;
@@ -787,6 +791,10 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             start_ray();
           }
         }
+      }
+      if (LDS_SCENE == 4 && P.prio_tiles != 0u) {  // A/B: issue priority for the waves that hold the frame's longest sample chains
+        if (__ballot(have_pixel && thin_pix) != 0ull) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
       }
     } else if (SPLIT_SHADE && pick == ST_SHADE2) {
       if (state == ST_SHADE2) shade(std::integral_constant<int, 2>{});
