@@ -510,6 +510,53 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     out.radius = round_up(radius + cabs);
     out.pad_k = round_up(8.0 * (8.0 * u + 2.0 * u) / rmin * 1.5 + 1e-12);
   }
+  // ---- four-wide form: fold every second level (the child with the largest box is replaced by its own two children until four are held)
+  out.qnodes.clear();
+  out.qroot = out.root;
+  if (out.root != NONE && !(out.root & FASTG_LEAF)) {
+    struct Cand {
+      float box[6];
+      uint32_t e;
+    };
+    out.qnodes.reserve(out.nodes.size() / 2 + 1);
+    std::function<uint32_t(uint32_t)> fold = [&](uint32_t n2) -> uint32_t {
+      Cand cs[4];
+      int nc = 0;
+      auto add = [&](const FastNodeG &nd, int side) {
+        std::memcpy(cs[nc].box, nd.box[side], sizeof cs[nc].box);
+        cs[nc].e = nd.child[side];
+        nc++;
+      };
+      add(out.nodes[n2], 0), add(out.nodes[n2], 1);
+      while (nc < 4) {
+        int pick = -1;
+        double best = -1.0;
+        for (int k = 0; k < nc; k++) {
+          if (cs[k].e & FASTG_LEAF) continue;
+          const float *b = cs[k].box;
+          double ex = (double)b[1] - b[0], ey = (double)b[3] - b[2], ez = (double)b[5] - b[4];
+          double area = ex * ey + ey * ez + ez * ex;
+          if (!(area <= best)) best = area, pick = k;  // NaN / inf areas count as largest
+        }
+        if (pick < 0) break;
+        const FastNodeG &nd = out.nodes[cs[pick].e];
+        cs[pick] = cs[nc - 1];
+        nc--;
+        add(nd, 0), add(nd, 1);
+      }
+      const uint32_t self = (uint32_t)out.qnodes.size();
+      out.qnodes.push_back(FastNodeQ{});
+      uint32_t ch[4] = {NONE, NONE, NONE, NONE};
+      for (int k = 0; k < nc; k++) ch[k] = (cs[k].e & FASTG_LEAF) ? cs[k].e : fold(cs[k].e);
+      FastNodeQ &q = out.qnodes[self];
+      for (int k = 0; k < 4; k++) {
+        for (int ax = 0; ax < 3; ax++) q.lo[ax][k] = k < nc ? cs[k].box[2 * ax] : 0.0f, q.hi[ax][k] = k < nc ? cs[k].box[2 * ax + 1] : 0.0f;
+        q.child[k] = ch[k];
+      }
+      return self;
+    };
+    out.qroot = fold(out.root);
+  }
   for (int ax = 0; ax < 3; ax++) out.center[ax] = (float)c[ax];
   out.r_safe = round_down(r_safe * 0.999 - 1e-6 * cabs);  // the device compares binary32 roundings of o and centre
   out.ok = out.r_safe > 0.0f;

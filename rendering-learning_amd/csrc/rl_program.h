@@ -132,12 +132,22 @@ bool build_fast_bvh(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, const 
 // Translate / Transform chain = one item per occurrence), boxes reject-only, nodes and items read from HBM / L2 / Infinity Cache.
 static const uint32_t FASTG_LEAF = 0x80000000u;  // child / entry: bit 31 set -> item index, else inner node index
 static const uint32_t FASTG_MAX_DEPTH = 40;      // the per-lane LDS stack holds 40 entries
-struct alignas(16) FastNodeG {
+struct alignas(16) FastNodeG {  // the binary tree as built (host side only; the device walks the four-wide form below)
   float box[2][6];    // [child][x.min, x.max, y.min, y.max, z.min, z.max], rounded outwards
   uint32_t child[2];
   uint32_t pad[2];
 };
 static_assert(sizeof(FastNodeG) == 64, "FastNodeG must be 64 B");
+// The same tree with every second level folded away — what the device walks: up to four children per node, 128 B = one L2 line (one
+// dependent fetch per TWO levels of the binary tree).  Children are the binary tree's, largest box expanded first; an empty slot has
+// child == NONE.
+struct alignas(16) FastNodeQ {
+  float lo[3][4];  // [axis][child], rounded outwards (the binary tree's own numbers)
+  float hi[3][4];
+  uint32_t child[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(FastNodeQ) == 128, "FastNodeQ must be 128 B");
 struct alignas(16) FastItem {
   uint32_t kind;     // 0 sphere, 1 planar
   uint32_t payload;  // sphere payload (index | SPH_MOVING | SPH_UV) or planar index
@@ -146,8 +156,10 @@ struct alignas(16) FastItem {
 };
 struct FastGeneral {
   std::vector<FastNodeG> nodes;
+  std::vector<FastNodeQ> qnodes;  // four-wide form of `nodes` (collapse_fast_general)
   std::vector<FastItem> items;
   uint32_t root = NONE;      // entry a new ray starts at (NONE: nothing to hit)
+  uint32_t qroot = NONE;     // ... in the four-wide form
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
   float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)
   float radius = 0, pad_k = 0;  // ... box growth for those rays = pad_k * (distance to centre + radius)^2 (world units)

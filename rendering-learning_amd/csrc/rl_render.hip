@@ -396,7 +396,7 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes))) ||
-      (H->fg.ok && ((rc = upload(H->fg.nodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items))))) {
+      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items))))) {
     destroy_one(s);
     return nullptr;
   }
@@ -571,7 +571,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   const uint32_t n_cops = (uint32_t)H.cops.size();
   P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
-  P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_root = H.fg.root, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
+  P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_root = H.fg.qroot, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;

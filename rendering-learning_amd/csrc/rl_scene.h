@@ -54,7 +54,7 @@ struct rl_scene {
   rl::CompactOp *d_cops = nullptr;
   uint32_t *d_movbits = nullptr;
   rl::FastNode *d_fast_nodes = nullptr;
-  rl::FastNodeG *d_fg_nodes = nullptr;
+  rl::FastNodeQ *d_fg_nodes = nullptr;
   rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
