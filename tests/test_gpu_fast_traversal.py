@@ -301,3 +301,29 @@ def test_general_scenes_fast_traversal_equals_reference_order_and_oracle(rl, ora
     assert report["cornell"][0] > 0                       # the coincident quads tie
     assert report["cow"][0] * 1000 < report["cow"][1]     # and the BASELINE scenes almost never fall back
     assert report["stress"][0] * 200 < report["stress"][1]
+
+
+def test_general_kernel_pending_list_overflow_falls_back_to_the_reference_order(rl, oracle):
+    """600 concentric glass / diffuse shells plus a quad (so the scene runs the general fast kernel): the surface-area heuristic peels
+    the shells one by one into a tree as deep as its budget, a ray towards the centre hits every box of it, and the list of pending
+    children outgrows the kernel's 20-entry LDS stack — such rays must be re-traced in the reference's order, not truncated."""
+
+    def shells(b):
+        glass, red = b.dielectric(1.3), b.lambertian(b.solid((0.7, 0.3, 0.3)))
+        objs = [b.sphere((0.0, 0.0, -3.0), 0.02 * 1.012 ** k, glass if k % 7 else red) for k in range(600)]
+        objs.append(b.quad((-4, -2.6, -7), (8, 0, 0), (0, 0, 8), b.lambertian(b.checker(0.8, b.solid((0.2, 0.2, 0.2)), b.solid((0.9, 0.9, 0.9))))))
+        return b.bvh(objs)
+
+    world = rl.World.build(shells)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=48, samples_per_pixel=4, max_depth=30, vfov=50.0, lookfrom=(0, 0.3, 2.0), lookat=(0, 0, -3),
+                        background=(0.6, 0.7, 0.9), seed=4)
+    cam = rl.Camera(p)
+    fast, ref_order, counting, st, gs = _frames(rl, cam, world)
+    assert _same_bits(fast, ref_order) and _same_bits(fast, counting)
+    cs = {}
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "rng_words", "flagged"):
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    assert np.abs(fast - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
+    print("slow traces", st["slow_traces"], "of", st["rays"])
+    assert st["slow_traces"] > 0
