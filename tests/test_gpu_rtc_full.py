@@ -80,3 +80,42 @@ def test_rtc_cylinders_cones_patterns_vs_oracle(rl, oracle):
         assert gs[k] == cs[k], (k, gs[k], cs[k])
     assert np.abs(img - cpu).max() <= TOL and np.abs(img - cpu).max() <= 1e-11
     assert img.max() > 0.2
+
+
+def test_rtc_reflection_depth_cap_is_loud_and_depth_7_matches_oracle(rl, oracle):
+    """A material that is reflective AND transparent spawns two rays per hit, so the kernel's depth-first walk needs
+    max_reflection_depth + 1 pending slots (RTC_MAX_PENDING = 8).  Depth 7 — the deepest world the library accepts — must match the
+    oracle's recursion (world.rs:128-159) counter for counter; depth 8 must be refused with RL_E_UNSUPPORTED, never truncated."""
+    api = rl.api
+    m = np.zeros(3, dtype=api.RTC_MATERIAL)
+    m["ambient"], m["diffuse"], m["specular"], m["shininess"], m["refractive_index"] = 0.1, 0.3, 0.9, 200.0, 1.0
+    m[0]["color"], m[0]["reflectivity"], m[0]["transparency"], m[0]["refractive_index"] = (0.9, 0.9, 1.0), 0.6, 0.8, 1.5  # glass-mirror
+    m[1]["color"], m[1]["reflectivity"], m[1]["transparency"], m[1]["refractive_index"] = (1.0, 0.8, 0.8), 0.5, 0.7, 1.3
+    m[2]["color"], m[2]["reflectivity"] = (0.3, 0.6, 0.3), 0.5
+    shapes = np.zeros(4, dtype=api.RTC_SHAPE)
+    shapes["kind"], shapes["material"] = [api.O_PLANE, api.O_SPHERE, api.O_SPHERE, api.O_CUBE], [2, 0, 1, 0]
+    T = lambda x, y, z: np.array([[1, 0, 0, x], [0, 1, 0, y], [0, 0, 1, z], [0, 0, 0, 1]], dtype=float)
+    S = lambda x, y, z: np.diag([x, y, z, 1.0])
+    tr = np.array([api.rtc_transformed(T(-1.1, 1, 0), api.O_SPHERE, 1), api.rtc_transformed(T(-1.1, 1, 0) @ S(0.5, 0.5, 0.5), api.O_SPHERE, 2),
+                   api.rtc_transformed(T(1.3, 0.8, 0.5) @ S(0.8, 0.8, 0.8), api.O_CUBE, 3)], dtype=api.RTC_TRANSFORMED)
+    objs = np.zeros(4, dtype=api.HREF)
+    objs["kind"], objs["index"] = [api.O_PLANE, api.O_TRANSFORMED, api.O_TRANSFORMED, api.O_TRANSFORMED], [0, 0, 1, 2]
+    lights = np.zeros(2, dtype=api.RTC_LIGHT)
+    lights["position"], lights["intensity"] = [(-5, 8, -8), (6, 5, -4)], [(0.7, 0.7, 0.7), (0.4, 0.4, 0.3)]
+    cam = api.rtc_camera(96, 64, 1.0, (0, 2.0, -6), (0, 0.8, 0), (0, 1, 0))
+
+    def build(depth):
+        return rl.RtcWorld.from_arrays(np.zeros(0, dtype=api.RTC_TRIANGLE), m, objs, lights, transformeds=tr, shapes=shapes, camera=cam,
+                                       max_reflection_depth=depth, void_color=(0.1, 0.1, 0.2))
+
+    world = build(7)
+    gs, cs = {}, {}
+    img = world.render(1, stats=gs)
+    cpu = oracle.rtc_render(world.desc, world.camera, aa=1, stats=cs)
+    for k in COUNTERS:
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    assert gs["rays"] > 40 * 96 * 64  # the tree really branches: two lights x two sub-rays per hit
+    assert np.abs(img - cpu).max() <= 1e-10
+    with pytest.raises(api.RLError) as e:
+        build(8).render(1)
+    assert "max_reflection_depth" in str(e.value), str(e.value)
