@@ -404,7 +404,15 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   }
   // ---- binned SAH build (16 bins per axis on the box centres), leaf = one item, depth <= FASTG_MAX_DEPTH
   out.items.resize(n);
-  for (size_t i = 0; i < n; i++) out.items[i] = items[i].it;
+  out.item_spheres.assign(n, DevSphere{});
+  out.item_material.assign(n, 0u);
+  for (size_t i = 0; i < n; i++) {
+    out.items[i] = items[i].it;
+    if (items[i].it.kind == 0) {
+      const uint32_t si = items[i].it.payload & SPH_INDEX;
+      out.item_spheres[i] = rt.spheres[si], out.item_material[i] = rt.sphere_material[si];
+    } else out.item_material[i] = rt.planars[items[i].it.payload].material;
+  }
   std::vector<uint32_t> ids(n);
   std::iota(ids.begin(), ids.end(), 0u);
   out.nodes.reserve(n);

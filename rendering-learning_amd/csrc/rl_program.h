@@ -158,6 +158,8 @@ struct FastGeneral {
   std::vector<FastNodeG> nodes;
   std::vector<FastNodeQ> qnodes;  // four-wide form of `nodes` (collapse_fast_general)
   std::vector<FastItem> items;
+  std::vector<DevSphere> item_spheres;  // [item]: the sphere record of a sphere item (zero for planars), so that LEAF fetches item and sphere side by side
+  std::vector<uint32_t> item_material;  // [item]: material index of the primitive
   uint32_t root = NONE;      // entry a new ray starts at (NONE: nothing to hit)
   uint32_t qroot = NONE;     // ... in the four-wide form
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest

@@ -194,7 +194,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -396,7 +396,7 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes))) ||
-      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items))))) {
+      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
     destroy_one(s);
     return nullptr;
   }
@@ -571,7 +571,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   const uint32_t n_cops = (uint32_t)H.cops.size();
   P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
-  P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_root = H.fg.qroot, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
+  P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_spheres = scene->d_fg_spheres, P.fg_material = scene->d_fg_material, P.fg_root = H.fg.qroot, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;

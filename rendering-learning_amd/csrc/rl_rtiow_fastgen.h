@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
 #endif
         const uint32_t item = pc & ~FASTG_LEAF;
         const FastItem it = items[item];
+        const DevSphere isph = P.fg_spheres[item];  // fetched side by side with the item (one round trip, not two)
         D3 o, d;
         replay_chain(P, ops, it.chain, wo, wd, o, d);
         // the tie band's coordinate scale max |o_k / d_k| of the ray the test actually sees (binary32 is plenty for a tolerance)
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
           oimax = fmaxf(fmaxf(fabsf((float)o.x * __builtin_amdgcn_rcpf((float)d.x)), fabsf((float)o.y * __builtin_amdgcn_rcpf((float)d.y))),
                         fabsf((float)o.z * __builtin_amdgcn_rcpf((float)d.z)));
         if (!(oimax < FINF)) oimax = FINF;  // NaN (0 * inf) -> every hit of this item counts as a tie
-        if (it.kind == 0) fastg_sphere_hit(P.spheres[it.payload & SPH_INDEX], it.payload, o, d, time, oimax, item, closest, best, amb);
+        if (it.kind == 0) fastg_sphere_hit(isph, it.payload, o, d, time, oimax, item, closest, best, amb);
         else fastg_planar_hit(P.planars[it.payload], o, d, oimax, item, closest, best, amb);
         go(pop());
       }
@@ -409,14 +410,14 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
           // the HitRecord of the winner: the same test once more with ray_t.max = its root (same arithmetic -> same root), then the
           // POP chain innermost first, as the reference's recursion unwinds (transform.rs:152-161, translate.rs:18)
           const FastItem it = items[best];
+          const DevSphere sp = P.fg_spheres[best];  // item, sphere record and material index side by side: one round trip
+          const uint32_t wmat = P.fg_material[best];
           D3 o, d;
           replay_chain(P, ops, it.chain, wo, wd, o, d);
           rec.t = closest;
           bool sensitive = false;
           if (it.kind == 0) {
-            uint32_t si = it.payload & SPH_INDEX;
-            const DevSphere &sp = P.spheres[si];
-            sphere_hit_rec(sp, it.payload, P.sphere_material[si], it.op_pc, o, d, time, rec);  // its flag: unreachable (r_safe)
+            sphere_hit_rec(sp, it.payload, wmat, it.op_pc, o, d, time, rec);  // its flag: unreachable (r_safe)
             D3 c0 = ld3(sp.c0);
             D3 center = (it.payload & SPH_MOVING) ? c0 + ld3(sp.dc) * time : c0;
             float oimax = ra32.oimax();

@@ -35,6 +35,8 @@ struct RtiowParams {
   const FastNode *fast_nodes;  // wave kernel LDS_SCENE = 4: the fast traversal structure (n_fast_inner nodes; entry ids, rl_program.h)
   uint32_t n_fast_inner, fast_root;
   const FastNodeQ *fg_nodes;  // rl_rtiow_fastgen.h: fast traversal structure of a general scene (rl_fast_bvh.cpp build_fast_general)
+  const DevSphere *fg_spheres;  // [item] sphere record of sphere items
+  const uint32_t *fg_material;   // [item] material index
   const FastItem *fg_items;
   uint32_t fg_root;
   float fg_center[3], fg_rsafe2;  // r_safe squared

@@ -56,6 +56,8 @@ struct rl_scene {
   rl::FastNode *d_fast_nodes = nullptr;
   rl::FastNodeQ *d_fg_nodes = nullptr;
   rl::FastItem *d_fg_items = nullptr;
+  rl::DevSphere *d_fg_spheres = nullptr;
+  uint32_t *d_fg_material = nullptr;
   rl::DevSphere *d_spheres = nullptr;
   uint32_t *d_sphere_material = nullptr;
   rl::DevPlanar *d_planars = nullptr;
