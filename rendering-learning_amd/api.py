@@ -306,6 +306,14 @@ class World:
         self.params = CameraParams._from_c(p)  # the example's / test's camera parameters
         self._device = None
 
+    def counts(self):
+        """Element counts of the flattened scene (rl_rtiow_scene_desc)."""
+        out = (C.c_uint32 * 9)()
+        L = host_lib()
+        L.rlh_rtiow_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.rlh_rtiow_counts(self._h, out)
+        return dict(zip(("spheres", "planars", "media", "translates", "transforms", "lists", "bvh_nodes", "materials", "textures"), list(out)))
+
     def __del__(self):
         try:
             if self._device is not None:
@@ -347,6 +355,21 @@ class World:
         rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
         h, w = rgb8.shape[:2]
         return World(L.rlh_rtiow_earth_scene(rgb8.ctypes.data, w, h))
+
+    @staticmethod
+    def example_scene(name: str, obj_text: bytes = None, rgb8: np.ndarray = None):
+        """The reference's other example scenes (host/scenes.hpp): "checkered_spheres", "quads", "flat_world", "cornell_box",
+        "cornell_smoke", "teapot" (obj_text = teapot-low.obj), "final_scene" (rgb8 = the earth image, sRGB8 [H, W, 3])."""
+        L = host_lib()
+        L.rlh_rtiow_example_scene.restype = C.c_void_p
+        L.rlh_rtiow_example_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32]
+        h = w = 0
+        ptr = None
+        if rgb8 is not None:
+            rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+            h, w = rgb8.shape[:2]
+            ptr = rgb8.ctypes.data
+        return World(L.rlh_rtiow_example_scene(name.encode(), obj_text, len(obj_text) if obj_text else 0, ptr, w, h))
 
     @staticmethod
     def stress_scene(n_side=1000, subdiv=2, obj_text: bytes = None, rgb8: np.ndarray = None, seed=5, device_bvh=False):

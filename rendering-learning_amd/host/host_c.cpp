@@ -79,6 +79,25 @@ rlh_rtiow *rlh_rtiow_earth_scene(const uint8_t *rgb8, uint32_t w, uint32_t h) {
     return nullptr;
   }
 }
+// The reference's remaining example scenes by name: "checkered_spheres", "quads", "flat_world", "cornell_box", "cornell_smoke",
+// "teapot" (obj_text = the OBJ), "final_scene" (rgb8 = the earth image, sRGB8).  Unused arguments may be NULL / 0.
+rlh_rtiow *rlh_rtiow_example_scene(const char *name, const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h) {
+  try {
+    std::string n(name ? name : "");
+    if (n == "checkered_spheres") return finish(scenes::checkered_spheres());
+    if (n == "quads") return finish(scenes::quads_scene(false));
+    if (n == "flat_world") return finish(scenes::quads_scene(true));
+    if (n == "cornell_box") return finish(scenes::cornell_scene(false));
+    if (n == "cornell_smoke") return finish(scenes::cornell_scene(true));
+    if (n == "teapot" && obj_text) return finish(scenes::teapot_scene(std::string(obj_text, obj_len)));
+    if (n == "final_scene" && rgb8) return finish(scenes::final_scene(rgb8, w, h));
+    g_err = "unknown example scene (or a missing OBJ / image): " + n;
+    return nullptr;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 // BASELINE configs[4] stress scene (scenes.hpp::stress_scene); obj_text may be NULL (spheres only)
 rlh_rtiow *rlh_rtiow_stress_scene(int n_side, int subdiv, const char *obj_text, uint64_t obj_len, const uint8_t *rgb8, uint32_t w, uint32_t h,
                                   uint64_t seed, int device_bvh) {
@@ -278,6 +297,12 @@ rlh_rtiow *rlh_b_finish(rlh_builder *b, int root) {
 
 const rl_rtiow_scene_desc *rlh_rtiow_desc(const rlh_rtiow *h) { return &h->desc; }
 void rlh_rtiow_free(rlh_rtiow *h) { delete h; }
+// element counts of the flattened scene: spheres, planars, media, translates, transforms, lists, bvh nodes, materials, textures
+void rlh_rtiow_counts(const rlh_rtiow *h, uint32_t out[9]) {
+  const rl_rtiow_scene_desc &d = h->desc;
+  const uint32_t v[9] = {d.n_spheres, d.n_planars, d.n_media, d.n_translates, d.n_transforms, d.n_lists, d.n_bvh_nodes, d.n_materials, d.n_textures};
+  for (int i = 0; i < 9; i++) out[i] = v[i];
+}
 
 void rlh_rtiow_get_params(const rlh_rtiow *h, rlh_camera_params *o) {
   const auto &p = h->params;

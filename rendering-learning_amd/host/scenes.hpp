@@ -5,6 +5,9 @@
 //   rtc_test_obj_scene     <- ray-tracer-challenge/tests/ray_tracer.rs:242-275
 //   rtiow WavefrontObj     <- ray-tracing-one-weekend/src/io/wavefront_obj.rs
 //   cow_scene              <- ray-tracing-one-weekend/examples/cow.rs:32-136
+//   checkered_spheres, quads_scene, cornell_scene, teapot_scene, final_scene, make_box
+//                          <- examples/checkered_spheres.rs, quads.rs, flat_world.rs, cornell_box.rs, cornell_smoke.rs, teapot.rs,
+//                             final_scene.rs, common/mod.rs:72-128
 #pragma once
 #include "rtc_host.hpp"
 #include "rtiow_host.hpp"
@@ -337,6 +340,177 @@ inline RtiowScene earth_scene(const uint8_t *rgb8, uint32_t tw, uint32_t th) {
   p.vup = Vec3(0.0, 1.0, 0.0);
   p.defocus_angle = 0.0;
   return RtiowScene{globe, p};
+}
+
+// ---- the reference's remaining example scenes (values restated; the example files themselves are drivers, not the hot path).
+// examples/common/mod.rs:72-128 make_box: the six sides (front, right, back, left, top, bottom) of the box spanned by two opposite
+// vertices, as a `[Quad; 6]` = a list hittable.
+inline rtiow::HittablePtr make_box(const rtiow::Point3 &a, const rtiow::Point3 &b, rtiow::MaterialPtr m) {
+  using namespace rtiow;
+  Point3 lo(std::fmin(a.x(), b.x()), std::fmin(a.y(), b.y()), std::fmin(a.z(), b.z()));
+  Point3 hi(std::fmax(a.x(), b.x()), std::fmax(a.y(), b.y()), std::fmax(a.z(), b.z()));
+  Vec3 dx(hi.x() - lo.x(), 0.0, 0.0), dy(0.0, hi.y() - lo.y(), 0.0), dz(0.0, 0.0, hi.z() - lo.z());
+  std::vector<HittablePtr> q;
+  q.push_back(std::make_shared<Quad>(Point3(lo.x(), lo.y(), hi.z()), dx, dy, m));
+  q.push_back(std::make_shared<Quad>(Point3(hi.x(), lo.y(), hi.z()), -dz, dy, m));
+  q.push_back(std::make_shared<Quad>(Point3(hi.x(), lo.y(), lo.z()), -dx, dy, m));
+  q.push_back(std::make_shared<Quad>(Point3(lo.x(), lo.y(), lo.z()), dz, dy, m));
+  q.push_back(std::make_shared<Quad>(Point3(lo.x(), hi.y(), hi.z()), dx, -dz, m));
+  q.push_back(std::make_shared<Quad>(Point3(lo.x(), lo.y(), lo.z()), dx, dz, m));
+  return std::make_shared<HittableList>(std::move(q));
+}
+
+inline rtiow::CameraParams cornell_camera() {  // cornell_box.rs:95-107 (= cornell_smoke.rs, cow.rs up to max_depth)
+  rtiow::CameraParams p;
+  p.aspect_ratio = 1.0, p.image_width = 600, p.samples_per_pixel = 200, p.max_depth = 50;
+  p.background = rtiow::Color(0.0, 0.0, 0.0);
+  p.vfov = 40.0;
+  p.lookfrom = rtiow::Point3(278.0, 278.0, -800.0), p.lookat = rtiow::Point3(278.0, 278.0, 0.0), p.vup = rtiow::Vec3(0.0, 1.0, 0.0);
+  p.defocus_angle = 0.0;
+  return p;
+}
+
+// examples/checkered_spheres.rs: two radius-10 spheres sharing one Checker Lambertian, a plain slice
+inline RtiowScene checkered_spheres() {
+  using namespace rtiow;
+  auto lambertian = Lambertian(Checker(0.32, SolidColor(Color(0.2, 0.3, 0.1)), SolidColor(Color(0.9, 0.9, 0.9))));
+  std::vector<HittablePtr> w;
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, -10.0, 0.0)), 10.0, lambertian));
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 10.0, 0.0)), 10.0, lambertian));
+  CameraParams p;
+  p.aspect_ratio = 16.0 / 9.0, p.image_width = 400, p.samples_per_pixel = 100, p.max_depth = 50, p.vfov = 20.0;
+  p.lookfrom = Point3(13.0, 2.0, 3.0), p.lookat = Point3(0.0, 0.0, 0.0), p.vup = Vec3(0.0, 1.0, 0.0), p.defocus_angle = 0.0;
+  return RtiowScene{std::make_shared<HittableList>(std::move(w)), p};
+}
+
+// examples/quads.rs (flat = false): five quads; examples/flat_world.rs (flat = true): the same room with the back wall a Triangle and
+// the floor an unbounded Plane with a Checker
+inline RtiowScene quads_scene(bool flat) {
+  using namespace rtiow;
+  auto left_red = Lambertian(SolidColor(Color(1.0, 0.2, 0.2)));
+  auto back_green = Lambertian(SolidColor(Color(0.2, 1.0, 0.2)));
+  auto right_blue = Lambertian(SolidColor(Color(0.2, 0.2, 1.0)));
+  auto upper_orange = Lambertian(SolidColor(Color(1.0, 0.5, 0.0)));
+  std::vector<HittablePtr> w;
+  w.push_back(std::make_shared<Quad>(Point3(-3.0, -2.0, 5.0), Vec3(0.0, 0.0, -4.0), Vec3(0.0, 4.0, 0.0), left_red));
+  if (flat) w.push_back(Triangle::from_quv(Point3(-2.0, -2.0, 0.0), Vec3(4.0, 0.0, 0.0), Vec3(0.0, 4.0, 0.0), back_green));
+  else w.push_back(std::make_shared<Quad>(Point3(-2.0, -2.0, 0.0), Vec3(4.0, 0.0, 0.0), Vec3(0.0, 4.0, 0.0), back_green));
+  w.push_back(std::make_shared<Quad>(Point3(3.0, -2.0, 1.0), Vec3(0.0, 0.0, 4.0), Vec3(0.0, 4.0, 0.0), right_blue));
+  w.push_back(std::make_shared<Quad>(Point3(-2.0, 3.0, 1.0), Vec3(4.0, 0.0, 0.0), Vec3(0.0, 0.0, 4.0), upper_orange));
+  if (flat) {
+    auto lower_checker = Lambertian(Checker(1.0, SolidColor(Color(0.2, 0.8, 0.8)), SolidColor(Color(0.8, 0.8, 0.8))));
+    w.push_back(std::make_shared<Plane>(Point3(-2.0, -3.0, 5.0), Vec3(4.0, 0.0, 0.0), Vec3(0.0, 0.0, -4.0), lower_checker));
+  } else {
+    auto lower_teal = Lambertian(SolidColor(Color(0.2, 0.8, 0.8)));
+    w.push_back(std::make_shared<Quad>(Point3(-2.0, -3.0, 5.0), Vec3(4.0, 0.0, 0.0), Vec3(0.0, 0.0, -4.0), lower_teal));
+  }
+  CameraParams p;
+  p.aspect_ratio = 1.0, p.image_width = 400, p.samples_per_pixel = 100, p.max_depth = 50, p.vfov = 80.0;
+  p.lookfrom = Point3(0.0, 0.0, 9.0), p.lookat = Point3(0.0, 0.0, 0.0), p.vup = Vec3(0.0, 1.0, 0.0), p.defocus_angle = 0.0;
+  return RtiowScene{std::make_shared<HittableList>(std::move(w)), p};
+}
+
+// examples/cornell_box.rs (smoke = false) / examples/cornell_smoke.rs (smoke = true: the two boxes become the boundaries of constant
+// media of density 0.01 — evaluated with the pixel's RNG stream, include/rl_render.h rl_medium); Bvh::new over everything
+inline RtiowScene cornell_scene(bool smoke) {
+  using namespace rtiow;
+  auto red = Lambertian(SolidColor(Color(0.65, 0.05, 0.05)));
+  auto white = Lambertian(SolidColor(Color(0.73, 0.73, 0.73)));
+  auto green = Lambertian(SolidColor(Color(0.12, 0.45, 0.15)));
+  auto light = DiffuseLight(SolidColor(smoke ? Color(7.0, 7.0, 7.0) : Color(15.0, 15.0, 15.0)));
+  std::vector<HittablePtr> w;
+  w.push_back(std::make_shared<Quad>(Point3(555, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), green));
+  w.push_back(std::make_shared<Quad>(Point3(0, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), red));
+  if (smoke) {
+    w.push_back(std::make_shared<Quad>(Point3(113, 554, 127), Vec3(330, 0, 0), Vec3(0, 0, 305), light));
+    w.push_back(std::make_shared<Quad>(Point3(0, 555, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+    w.push_back(std::make_shared<Quad>(Point3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+  } else {
+    w.push_back(std::make_shared<Quad>(Point3(343, 554, 332), Vec3(-130, 0, 0), Vec3(0, 0, -105), light));
+    w.push_back(std::make_shared<Quad>(Point3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+    w.push_back(std::make_shared<Quad>(Point3(555, 555, 555), Vec3(-555, 0, 0), Vec3(0, 0, -555), white));
+  }
+  w.push_back(std::make_shared<Quad>(Point3(0, 0, 555), Vec3(555, 0, 0), Vec3(0, 555, 0), white));
+  HittablePtr box1 = std::make_shared<Translate>(Transform::rotate_y(make_box(Point3(0, 0, 0), Point3(165, 330, 165), white), 15.0), Vec3(265, 0, 295));
+  HittablePtr box2 = std::make_shared<Translate>(Transform::rotate_y(make_box(Point3(0, 0, 0), Point3(165, 165, 165), white), -18.0), Vec3(130, 0, 65));
+  if (smoke) {
+    w.push_back(std::make_shared<ConstantMedium>(box1, 0.01, Isotropic(SolidColor(Color(0.0, 0.0, 0.0)))));
+    w.push_back(std::make_shared<ConstantMedium>(box2, 0.01, Isotropic(SolidColor(Color(1.0, 1.0, 1.0)))));
+  } else {
+    w.push_back(box1);
+    w.push_back(box2);
+  }
+  return RtiowScene{std::make_shared<Bvh>(std::move(w)), cornell_camera()};
+}
+
+// examples/teapot.rs: the OBJ under scale(2) -> rotate_x(-90) next to a sphere light, Bvh::new over the two
+inline RtiowScene teapot_scene(const std::string &obj_text) {
+  using namespace rtiow;
+  auto diffuse = Lambertian(SolidColor(Color(0.53, 0.32, 0.75)));
+  auto light = DiffuseLight(SolidColor(Color(5.0, 5.0, 5.0)));
+  auto teapot = RtiowObj::parse(obj_text).to_object(diffuse);
+  std::vector<HittablePtr> w;
+  w.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(40.0, 20.0, -40.0)), 10.0, light));
+  w.push_back(Transform::rotate_x(Transform::scale(teapot, 2.0), -90.0));
+  CameraParams p;
+  p.aspect_ratio = 1.0, p.image_width = 600, p.samples_per_pixel = 200, p.max_depth = 40, p.vfov = 40.0;
+  p.lookfrom = Point3(0.0, 0.0, -100.0), p.lookat = Point3(0.0, 0.0, 0.0), p.vup = Vec3(0.0, 1.0, 0.0), p.defocus_angle = 0.0;
+  p.background = Color(0.1, 0.1, 0.1);
+  return RtiowScene{std::make_shared<Bvh>(std::move(w)), p};
+}
+
+// examples/final_scene.rs ("The Next Week"): Xoshiro256++ seed 0 drives, in this order, Perlin::new, the 400 floor-box heights
+// (gen_range(1.0..101.0)) and the 1000 sphere centres (Point3::random_in_range(0, 165): x, y, z).  The earth image is the caller's
+// (sRGB8; the example embeds earthmap.jpg, JPEG decoding is out of scope).  The world is a plain slice of boxed hittables.
+inline RtiowScene final_scene(const uint8_t *rgb8, uint32_t tw, uint32_t th) {
+  using namespace rtiow;
+  auto rng = Xoshiro256PlusPlus::seed_from_u64(0);
+  auto ground_material = Lambertian(SolidColor(Color(0.48, 0.83, 0.53)));
+  auto light_material = DiffuseLight(SolidColor(Color(7.0, 7.0, 7.0)));
+  auto sphere_material = Lambertian(SolidColor(Color(0.7, 0.3, 0.1)));
+  auto glass_material = Dielectric(1.5);
+  auto metal_material = Metal(Color(0.8, 0.8, 0.9), 1.0);
+  auto subsurface_material = Isotropic(SolidColor(Color(0.2, 0.4, 0.9)));
+  auto fog_material = Isotropic(SolidColor(Color(1.0, 1.0, 1.0)));
+  auto img = std::make_shared<ImageData>();
+  img->width = tw, img->height = th;
+  img->rgb.resize((size_t)tw * th * 3);
+  for (size_t i = 0; i < img->rgb.size(); i++) img->rgb[i] = (float)srgb::srgb_to_linear((double)((float)rgb8[i] / 255.0f));
+  auto earth_material = Lambertian(Image(img));
+  auto perlin_material = Lambertian(Noise(Perlin::create(rng), 0.2));
+  auto white_material = Lambertian(SolidColor(Color(0.73, 0.73, 0.73)));
+  std::vector<HittablePtr> world;
+  std::vector<HittablePtr> boxes;
+  for (int i = 0; i < 20; i++)
+    for (int j = 0; j < 20; j++) {
+      double w = 100.0, x0 = -1000.0 + (double)i * w, z0 = -1000.0 + (double)j * w, y0 = 0.0;
+      double x1 = x0 + w, y1 = rng.gen_range(1.0, 101.0), z1 = z0 + w;
+      boxes.push_back(make_box(Point3(x0, y0, z0), Point3(x1, y1, z1), ground_material));
+    }
+  world.push_back(std::make_shared<Bvh>(std::move(boxes)));
+  world.push_back(std::make_shared<Quad>(Point3(123.0, 554.0, 147.0), Vec3(300.0, 0.0, 0.0), Vec3(0.0, 0.0, 265.0), light_material));
+  Point3 center1(400.0, 400.0, 200.0);
+  world.push_back(std::make_shared<Sphere>(Center::Moving(center1, center1 + Vec3(30.0, 0.0, 0.0)), 50.0, sphere_material));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(260.0, 150.0, 45.0)), 50.0, glass_material));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 150.0, 145.0)), 50.0, metal_material));
+  auto subsurface_boundary = [&]() { return std::make_shared<Sphere>(Center::Stationary(Point3(360.0, 150.0, 145.0)), 70.0, glass_material); };
+  world.push_back(subsurface_boundary());
+  world.push_back(std::make_shared<ConstantMedium>(subsurface_boundary(), 0.2, subsurface_material));
+  world.push_back(std::make_shared<ConstantMedium>(std::make_shared<Sphere>(Center::Stationary(Point3(0.0, 0.0, 0.0)), 5000.0, glass_material), 0.0001, fog_material));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(400.0, 200.0, 400.0)), 100.0, earth_material));
+  world.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(220.0, 280.0, 300.0)), 80.0, perlin_material));
+  std::vector<HittablePtr> boxes2;
+  for (int k = 0; k < 1000; k++) {
+    double x = rng.gen_range(0.0, 165.0), y = rng.gen_range(0.0, 165.0), z = rng.gen_range(0.0, 165.0);
+    boxes2.push_back(std::make_shared<Sphere>(Center::Stationary(Point3(x, y, z)), 10.0, white_material));
+  }
+  world.push_back(std::make_shared<Translate>(Transform::rotate_y(std::make_shared<Bvh>(std::move(boxes2)), 15.0), Vec3(-100.0, 270.0, 395.0)));
+  CameraParams p;
+  p.aspect_ratio = 1.0, p.image_width = 400, p.samples_per_pixel = 250, p.max_depth = 4;  // the example's "dev" parameters
+  p.background = Color(0.0, 0.0, 0.0);
+  p.vfov = 40.0;
+  p.lookfrom = Point3(478.0, 278.0, -600.0), p.lookat = Point3(278.0, 278.0, 0.0), p.vup = Vec3(0.0, 1.0, 0.0), p.defocus_angle = 0.0;
+  return RtiowScene{std::make_shared<HittableList>(std::move(world)), p};
 }
 
 // BASELINE configs[4] ("1M random spheres + 100k-triangle OBJ"): NOT in the reference — defined by

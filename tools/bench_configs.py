@@ -91,6 +91,13 @@ if "rtcfull" in which:  # not a BASELINE config: the reference's mirror / CSG in
         cpu = oracle.rtc_render(w.desc, w.camera, aa=1, row_first=0, row_step=60)
         print(json.dumps({"config": name, "aa": 1, "rays": st["rays"], "kernel_ms": st["kernel_ms"], "Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
                           "max_abs_err_vs_oracle_rows": float(np.abs(img[0::60] - cpu).max())}), flush=True)
+if "examples" in which:  # not BASELINE configs: the reference's other example scenes at the examples' own sizes (host/scenes.hpp)
+    tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
+    for name, kw in (("checkered_spheres", {}), ("quads", {}), ("flat_world", {}), ("cornell_box", {}), ("cornell_smoke", {}),
+                     ("teapot", dict(obj_text=open(os.path.join(G, "teapot-low.obj"), "rb").read())), ("final_scene", dict(rgb8=tex))):
+        w = rl.World.example_scene(name, **kw)
+        p = w.params
+        rtiow("examples/%s.rs %dx%d" % (name, p.image_width, int(p.image_width / p.aspect_ratio)), w, p, 50)
 if "cfg4" in which or "cfg5" in which:
     tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
     obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
