@@ -239,6 +239,36 @@ struct GItem {
 
 }  // namespace
 
+// Squared distance from the origin to the triangle (a, b, c): vertices, clamped edge projections, and the plane projection when it falls inside
+static double min_norm2_on_triangle(const double *a, const double *b, const double *c) {
+  auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+  double best = std::fmin(dot3(a, a), std::fmin(dot3(b, b), dot3(c, c)));
+  const double *e[3][2] = {{a, b}, {b, c}, {c, a}};
+  for (auto &pq : e) {
+    double dq[3] = {pq[1][0] - pq[0][0], pq[1][1] - pq[0][1], pq[1][2] - pq[0][2]};
+    double l2 = dot3(dq, dq);
+    if (!(l2 > 0.0)) continue;
+    double t = std::fmin(1.0, std::fmax(0.0, -dot3(pq[0], dq) / l2));
+    double p[3] = {pq[0][0] + t * dq[0], pq[0][1] + t * dq[1], pq[0][2] + t * dq[2]};
+    best = std::fmin(best, dot3(p, p));
+  }
+  double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+  double nn[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+  double n2 = dot3(nn, nn);
+  if (n2 > 0.0) {
+    double k = dot3(a, nn) / n2;
+    double p[3] = {nn[0] * k, nn[1] * k, nn[2] * k};  // projection of the origin onto the plane
+    double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    double d00 = dot3(ab, ab), d01 = dot3(ab, ac), d11 = dot3(ac, ac), d20 = dot3(ap, ab), d21 = dot3(ap, ac);
+    double den = d00 * d11 - d01 * d01;
+    if (den > 0.0) {
+      double v = (d11 * d20 - d01 * d21) / den, w = (d00 * d21 - d01 * d20) / den;
+      if (v >= 0.0 && w >= 0.0 && v + w <= 1.0) best = std::fmin(best, dot3(p, p));
+    }
+  }
+  return best;
+}
+
 bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out) {
   out = FastGeneral{};
   if (rt.has_media) return false;  // a ConstantMedium draws from the RNG while the world is traversed: the reference's order is part of its result
@@ -315,12 +345,15 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     add_points(g, pts, pl.kind == RL_PLANAR_QUAD ? 4 : 3);
     if (pl.kind == RL_PLANAR_TRIANGLE && pl.has_normals) {  // triangle.rs:78-83: unit(n2 a + n3 b + n1 (1-a-b)) must not come near zero
       const double *n = pl.normals;
+      double lmax = 0.0;
       for (int i = 0; i < 3; i++) {
         double l2 = n[3 * i] * n[3 * i] + n[3 * i + 1] * n[3 * i + 1] + n[3 * i + 2] * n[3 * i + 2];
         if (!(l2 >= 1e-6 && l2 <= 1e6)) return false;
-        for (int j = i + 1; j < 3; j++)
-          if (!(n[3 * i] * n[3 * j] + n[3 * i + 1] * n[3 * j + 1] + n[3 * i + 2] * n[3 * j + 2] > 0.0)) return false;
+        lmax = std::fmax(lmax, l2);
       }
+      // the interpolated normal ranges over the triangle spanned by the three vertex normals: its shortest vector must stay well away
+      // from zero (at least 1 % of the longest vertex normal)
+      if (!(min_norm2_on_triangle(n, n + 3, n + 6) >= 1e-4 * lmax)) return false;
     }
     items.push_back(g);
     return true;

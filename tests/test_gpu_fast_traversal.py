@@ -327,3 +327,32 @@ def test_general_kernel_pending_list_overflow_falls_back_to_the_reference_order(
     assert np.abs(fast - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
     print("slow traces", st["slow_traces"], "of", st["rays"])
     assert st["slow_traces"] > 0
+
+
+def test_vanishing_interpolated_normals_keep_the_reference_order(rl, oracle):
+    """triangle.rs:78-83 normalises n2 a + n3 b + n1 (1 - a - b).  Vertex normals that merely point apart (the teapot's lid: pairwise
+    dot products <= 0, shortest interpolated normal 0.43) are fine for the fast traversal; a triangle whose interpolated normal passes
+    through zero is a reference panic site whose count depends on the visiting order, so such a scene must stay on the reference-order
+    kernels — either way the frames and the panic-site count equal the oracle's."""
+
+    def scene(vanishing):
+        def build(b):
+            mat = b.lambertian(b.solid((0.7, 0.6, 0.5)))
+            apart = b.triangle_from_model([[-1, 0, -3], [1, 0, -3], [0, 1.5, -3]], mat, normals=[[-0.8, 0, 0.6], [0.8, 0, 0.6], [0, 0.9, 0.45]])
+            n3 = [0, 0, -1] if vanishing else [0, 0.6, 0.8]
+            other = b.triangle_from_model([[-1, -1.6, -2.5], [1, -1.6, -2.5], [0, -0.2, -2.5]], mat, normals=[[0, 0, 1], [0.6, 0, 0.8], n3])
+            return b.bvh([apart, other, b.quad((-3, -1.7, -5), (6, 0, 0), (0, 0, 5), mat), b.sphere((0, 0.3, -1.5), 0.2, b.dielectric(1.5))])
+        return rl.World.build(build)
+
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=64, samples_per_pixel=8, max_depth=8, vfov=70.0, lookfrom=(0, 0, 1), lookat=(0, 0, -3),
+                        background=(0.5, 0.6, 0.8), seed=2)
+    cam = rl.Camera(p)
+    for vanishing in (False, True):
+        world = scene(vanishing)
+        fast, ref_order, counting, st, gs = _frames(rl, cam, world, allow_degenerate=True)
+        assert _same_bits(fast, ref_order) and _same_bits(fast, counting), vanishing
+        cs = {}
+        cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+        for k in ("rays", "node_tests", "planar_tests", "rng_words", "flagged"):
+            assert gs[k] == cs[k], (vanishing, k, gs[k], cs[k])
+        assert np.nanmax(np.abs(fast - cpu)) <= 1e-9 * max(1.0, np.nanmax(np.abs(cpu))), vanishing

@@ -1,0 +1,18 @@
+import importlib, os, sys, time, numpy as np, torch
+ROOT="/root/repo"; sys.path.insert(0, ROOT)
+rl = importlib.import_module("rendering-learning_amd"); rl.init(0)
+G=os.path.join(ROOT,"tests","golden")
+w = rl.World.example_scene("teapot", obj_text=open(os.path.join(G,"teapot-low.obj"),"rb").read())
+p = w.params
+if len(sys.argv)>1: p.samples_per_pixel=int(sys.argv[1])
+if len(sys.argv)>2: p.max_depth=int(sys.argv[2])
+if len(sys.argv)>3: p.image_width=int(sys.argv[3])
+cam = rl.Camera(p)
+dev=torch.device("cuda",0)
+buf=torch.zeros((cam.c.image_height,cam.c.image_width,3),dtype=torch.float64,device=dev)
+s=torch.cuda.current_stream(dev)
+for i in range(2):
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record(s); cam.render_device(w, buf.data_ptr(), stream=s.cuda_stream); e1.record(s)
+    st=rl.api.render_status(w); torch.cuda.synchronize()
+print(sys.argv[1:], os.environ.get("RL_RTIOW_KERNEL","default"), os.environ.get("RL_FAST",""), os.environ.get("RL_LPT",""), "ms", round(e0.elapsed_time(e1),1), "rays", st["rays"], "Mrays/s", round(st["rays"]/e0.elapsed_time(e1)/1e3,1))
