@@ -672,7 +672,12 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     if (variant == 2) {
       constexpr int NT = 256;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
-      rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+      // register budget of two waves per SIMD (256 registers instead of 256 + 151): cornell_smoke 309 -> 493 Mrays/s, final_scene 170 -> 219
+      // (three waves: 390 / 182).  RL_GENERAL_REGS=256|768 selects the others (A/B).
+      static const int regs = std::getenv("RL_GENERAL_REGS") ? std::atoi(std::getenv("RL_GENERAL_REGS")) : 512;
+      if (regs == 512) rc = want_stats ? launch(rtiow_general_kernel<NT, true, 512>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 512>, NT, rb, false);
+      else if (regs == 768) rc = want_stats ? launch(rtiow_general_kernel<NT, true, 768>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 768>, NT, rb, false);
+      else rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
     } else if (variant == 1031) {  // rings + the traversal stacks in LDS
       // four steps per scheduling round (a step is an Infinity Cache / L2 round trip here, not an LDS one: lanes that fall out of TRAV
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24

@@ -2,7 +2,10 @@ import importlib, os, sys, time, numpy as np, torch
 ROOT="/root/repo"; sys.path.insert(0, ROOT)
 rl = importlib.import_module("rendering-learning_amd"); rl.init(0)
 G=os.path.join(ROOT,"tests","golden")
-w = rl.World.example_scene("teapot", obj_text=open(os.path.join(G,"teapot-low.obj"),"rb").read())
+name = os.environ.get("SCENE", "teapot")
+from PIL import Image
+kw = {"teapot": dict(obj_text=open(os.path.join(G,"teapot-low.obj"),"rb").read()), "final_scene": dict(rgb8=np.asarray(Image.open(os.path.join(G,"spot_texture.png")).convert("RGB")))}.get(name, {})
+w = rl.World.example_scene(name, **kw)
 p = w.params
 if len(sys.argv)>1: p.samples_per_pixel=int(sys.argv[1])
 if len(sys.argv)>2: p.max_depth=int(sys.argv[2])
@@ -15,4 +18,4 @@ for i in range(2):
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     e0.record(s); cam.render_device(w, buf.data_ptr(), stream=s.cuda_stream); e1.record(s)
     st=rl.api.render_status(w); torch.cuda.synchronize()
-print(sys.argv[1:], os.environ.get("RL_RTIOW_KERNEL","default"), os.environ.get("RL_FAST",""), os.environ.get("RL_LPT",""), "ms", round(e0.elapsed_time(e1),1), "rays", st["rays"], "Mrays/s", round(st["rays"]/e0.elapsed_time(e1)/1e3,1))
+print(name, sys.argv[1:], os.environ.get("RL_GENERAL_REGS",""), os.environ.get("RL_RTIOW_KERNEL","default"), os.environ.get("RL_FAST",""), os.environ.get("RL_LPT",""), "ms", round(e0.elapsed_time(e1),1), "rays", st["rays"], "Mrays/s", round(st["rays"]/e0.elapsed_time(e1)/1e3,1))
