@@ -618,9 +618,9 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
   int variant = g_rtiow_variant;
   bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
-  // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: only the nested-loop all-primitives kernel
-  // evaluates it (reference order by construction); no fast traversal, no cost-sorted resume
-  if (rt.has_media) variant = 2;
+  // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: the reference-order kernels evaluate it (the
+  // wave-scheduled one as a scope of the threaded program, the nested-loop one by recursion: RL_RTIOW_KERNEL=general); no fast traversal
+  if (rt.has_media && variant != 2) variant = 4;
 #ifndef RL_EXPERIMENTAL
   if (variant == 3 || variant == 5 || variant == 6 || variant == 7) return set_err(RL_E_UNSUPPORTED, "experimental kernel variants live in librl_render_exp.so only");
 #endif
@@ -700,7 +700,11 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       int gnt = 512;
       if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);
       size_t rb = (size_t)16 * gnt * sizeof(unsigned long long);
-      if (trans && gnt == 768) rc = want_stats ? launch(rtiow_wave_general_kernel<768, true, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, true, false>, 768, rb, false);
+      if (rt.has_media) {  // + the parked HitRecord of a medium scope: 96 B of LDS per lane
+        size_t mb = (size_t)512 * (16 + MEDIA_SAVE_WORDS) * sizeof(unsigned long long);
+        if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true, true>, 512, mb, false) : launch(rtiow_wave_general_kernel<512, true, false, true>, 512, mb, false);
+        else rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true, true>, 512, mb, false) : launch(rtiow_wave_general_kernel<512, false, false, true>, 512, mb, false);
+      } else if (trans && gnt == 768) rc = want_stats ? launch(rtiow_wave_general_kernel<768, true, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, true, false>, 768, rb, false);
       else if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, true, false>, 512, rb, false);
       else if (gnt == 512) rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, false, false>, 512, rb, false);
       else rc = want_stats ? launch(rtiow_wave_general_kernel<768, false, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, false, false>, 768, rb, false);

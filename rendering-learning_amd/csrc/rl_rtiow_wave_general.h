@@ -18,11 +18,19 @@ enum : uint32_t { ST_XF = 6 };
 
 // TRANS: the scene needs the transcendental texture code (Noise, or Image textures on spheres -> get_sphere_uv); without it
 // the kernel fits 168 VGPRs (3 waves per SIMD) instead of 256 (2 waves per SIMD)
-template <int NT, bool TRANS, bool STATS>
+// MEDIA: the scene holds ConstantMedium hittables (constant_medium.rs:27-80, the deterministic variant of include/rl_render.h rl_medium).
+// A medium is a SCOPE of the threaded program, like an instance: OP_MEDIUM_BEGIN parks the closest hit found so far in LDS and walks the
+// boundary's ops with ray_t = universe; OP_MEDIUM_END either restarts the walk with ray_t = (t1 + 0.0001, inf) (first pass found a hit)
+// or closes the scope: the parked record comes back, and with both boundary hits the free path is drawn from the pixel's stream exactly
+// where the reference's traversal evaluates the medium.  Boxes inside the scope are tested with the reference's divisions (the
+// filtered test is derived for [1e-10, closest]).  Media do not nest (rl_program.cpp).
+static const int MEDIA_SAVE_WORDS = 12;  // parked Rec: t, p, normal, u, v, w, {mat, pc}, flags
+template <int NT, bool TRANS, bool STATS, bool MEDIA = false>
 __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;  // [16][NT]
+  unsigned long long *s_save = s_rng + (size_t)16 * NT;    // [MEDIA_SAVE_WORDS][NT] (MEDIA only)
   const DevOp *ops = P.ops;
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
@@ -47,6 +55,29 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
   uint32_t pc = 0, depth = 0;
   uint32_t c_rays = 0, c_flag = 0;
   unsigned long long c_nodes = 0, c_sph = 0, c_pl = 0, c_inst = 0, c_words = 0;
+  // MEDIA: ray_t.min of the current walk (1e-10 outside a medium scope), the scope's pass (0 = none) and the first pass's hit distance
+  double tmin = 1e-10, m_t1 = 0.0;
+  uint32_t mphase = 0;
+  auto fresh_rec = [&]() { rec.t = INF, rec.any = false, rec.pc = 0; };
+  auto park_rec = [&]() {
+    auto st = [&](int k, unsigned long long v) { s_save[(size_t)k * NT + tid] = v; };
+    auto bits = [](double x) { return (unsigned long long)__double_as_longlong(x); };
+    st(0, bits(rec.t)), st(1, bits(rec.p.x)), st(2, bits(rec.p.y)), st(3, bits(rec.p.z));
+    st(4, bits(rec.normal.x)), st(5, bits(rec.normal.y)), st(6, bits(rec.normal.z));
+    st(7, bits(rec.u)), st(8, bits(rec.v)), st(9, bits(rec.w));
+    st(10, (unsigned long long)rec.mat | ((unsigned long long)rec.pc << 32));
+    st(11, (rec.front ? 1ull : 0ull) | (rec.any ? 2ull : 0ull) | (rec.uv3 ? 4ull : 0ull));
+  };
+  auto unpark_rec = [&]() {
+    auto ld = [&](int k) { return s_save[(size_t)k * NT + tid]; };
+    auto dbl = [](unsigned long long x) { return __longlong_as_double((long long)x); };
+    rec.t = dbl(ld(0)), rec.p = d3(dbl(ld(1)), dbl(ld(2)), dbl(ld(3)));
+    rec.normal = d3(dbl(ld(4)), dbl(ld(5)), dbl(ld(6)));
+    rec.u = dbl(ld(7)), rec.v = dbl(ld(8)), rec.w = dbl(ld(9));
+    unsigned long long mp = ld(10), fl = ld(11);
+    rec.mat = (uint32_t)mp, rec.pc = (uint32_t)(mp >> 32);
+    rec.front = (fl & 1ull) != 0ull, rec.any = (fl & 2ull) != 0ull, rec.uv3 = (fl & 4ull) != 0ull;
+  };
 
   for (;;) {
     int n_trav = __popcll(__ballot(state == ST_TRAV));
@@ -75,7 +106,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
           bool is_box = (kind == OP_BOX) | (kind == OP_BOX_SPH) | (kind == OP_BOX_PLANAR);
           bool certain;
           bool hitb = aabb_fast(bx, ra, rec.t, certain);
-          if (is_box && !(certain && ra.fast_ok && (code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, 1e-10, rec.t);
+          if (MEDIA && mphase != 0u) certain = false;  // inside a medium scope ray_t.min is not 1e-10: the reference's own test
+          if (is_box && !(certain && ra.fast_ok && (code & BOX_FINITE))) hitb = aabb_hit(bx, o, d, MEDIA ? tmin : 1e-10, rec.t);
           if (STATS) c_nodes += is_box ? 1u : 0u;
           bool leaf_kind = (kind == OP_BOX_SPH) | (kind == OP_BOX_PLANAR);
           bool to_leaf = (kind == OP_SPHERE) | (kind == OP_PLANAR) | (leaf_kind & hitb);
@@ -95,18 +127,18 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
         if (kind == OP_BOX_SPH || kind == OP_SPHERE) {
           uint32_t ai = a & SPH_INDEX;
           if (STATS) c_sph++;
-          if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec)) c_flag++;
+          if (sphere_hit_rec(P.spheres[ai], a, P.sphere_material[ai], pc, o, d, time, rec, MEDIA ? tmin : 1e-10)) c_flag++;
           if (b != NONE) {
             uint32_t bi = b & SPH_INDEX;
             if (STATS) c_sph++;
-            if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec)) c_flag++;
+            if (sphere_hit_rec(P.spheres[bi], b, P.sphere_material[bi], pc, o, d, time, rec, MEDIA ? tmin : 1e-10)) c_flag++;
           }
         } else {
           if (STATS) c_pl++;
-          if (planar_hit_rec(P.planars[a], pc, o, d, rec)) c_flag++;
+          if (planar_hit_rec(P.planars[a], pc, o, d, rec, MEDIA ? tmin : 1e-10)) c_flag++;
           if (b != NONE) {
             if (STATS) c_pl++;
-            if (planar_hit_rec(P.planars[b], pc, o, d, rec)) c_flag++;
+            if (planar_hit_rec(P.planars[b], pc, o, d, rec, MEDIA ? tmin : 1e-10)) c_flag++;
           }
         }
         pc = op.skip;
@@ -116,7 +148,39 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
       if (state == ST_XF) {
         const DevOp &op = ops[pc];
         uint32_t kind = op.code & 0xFFu;
-        if (kind == OP_PUSH_TRANSLATE) {
+        uint32_t next_pc = pc + 1u;
+        if (MEDIA && kind == OP_MEDIUM_BEGIN) {  // boundary.hit(r, universe)
+          park_rec();
+          fresh_rec();
+          tmin = -INF, mphase = 1u;
+        } else if (MEDIA && kind == OP_MEDIUM_END) {
+          if (mphase == 1u && rec.any) {  // boundary.hit(r, (rec1.t + 0.0001, inf)): the same ops once more
+            m_t1 = rec.t;
+            fresh_rec();
+            tmin = m_t1 + 1e-4, mphase = 2u;
+            next_pc = op.b + 1u;
+          } else {
+            const bool both = mphase == 2u && rec.any;
+            const double t_exit = rec.t;
+            unpark_rec();
+            tmin = 1e-10, mphase = 0u;
+            if (both) {  // constant_medium.rs:43-80 with ray_t = [1e-10, closest so far]
+              const rl_medium &m = P.media[op.a];
+              double t1 = fmax(m_t1, 1e-10), t2 = fmin(t_exit, rec.t);
+              if (!(t1 >= t2)) {
+                t1 = fmax(t1, 0.0);
+                double ray_length = sqrt(len2(d));
+                double distance_inside_boundary = (t2 - t1) * ray_length;
+                double hit_distance = m.neg_inv_density * log(rng.gen_f64());
+                if (!(hit_distance > distance_inside_boundary)) {
+                  double t = t1 + hit_distance / ray_length;
+                  rec.t = t, rec.p = o + d * t, rec.normal = d3(1.0, 0.0, 0.0), rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false;
+                  rec.front = true, rec.mat = m.material, rec.pc = op.b, rec.any = true;
+                }
+              }
+            }
+          }
+        } else if (kind == OP_PUSH_TRANSLATE) {
           if (STATS) c_inst++;
           o = o - ld3(P.translates[op.a].offset);
         } else if (kind == OP_PUSH_TRANSFORM) {
@@ -140,7 +204,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
           replay_chain(P, ops, ops[push_pc].b, wo, wd, o, d);
         }
         ra = ray_aux(o, d);
-        pc++;
+        pc = next_pc;
         state = ST_TRAV;
       }
     } else if (pick == ST_FILL) {
@@ -233,14 +297,17 @@ __global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
           // texture first (it draws no random numbers): the transcendental code in here (acos / atan2 for sphere UVs, sin and
           // Perlin for Noise) is register-hungry, so it runs before the scatter temporaries are live
           D3 texc = d3(0.0, 0.0, 0.0);
-          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT || (MEDIA && m.kind == RL_MAT_ISOTROPIC)) {
             double tu, tv;
             rec_uv<TRANS>(rec, tu, tv);
             texc = texture_value<(TRANS ? 2 : 1)>(P, m.texture, tu, tv, rec.p);
           }
           uint32_t kind = m.kind;
           D3 normal = rec.normal;
-          if (kind == RL_MAT_LAMBERTIAN) {
+          if (MEDIA && kind == RL_MAT_ISOTROPIC) {  // material.rs:201-214: Vec3::random_unit_vector, attenuation = texture.value(uv, p)
+            nd = rng.unit_sphere();
+            thr = thr * texc;
+          } else if (kind == RL_MAT_LAMBERTIAN) {
             D3 dir = normal + rng.unit_sphere();
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;

@@ -125,3 +125,37 @@ def test_gpu_medium_row_shards_and_first_sample(rl, oracle):
     part = cam.render_rows(world, 0, 1, first_sample=9)
     cpu = oracle.rtiow_render(world.desc, cam.c, first_sample=9)
     assert np.abs(part - cpu).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp", [6, 72])
+def test_gpu_wave_scheduled_medium_scope_equals_nested_loop_kernel(rl, oracle, spp):
+    """The wave-scheduled kernel evaluates a ConstantMedium as a scope of the threaded program (park the closest hit, walk the boundary
+    twice, draw the free path); the nested-loop kernel (RL_RTIOW_KERNEL=general) does it by recursion.  Same frames, same counters —
+    also through the cost-sorted two-launch render (spp 72) and for the counter-free instantiation."""
+    import torch
+    world = rl.World.build(_smoke_scene)
+    p = rl.CameraParams(aspect_ratio=1.0, image_width=64, samples_per_pixel=spp, max_depth=20, vfov=40.0, lookfrom=(278, 278, -800), lookat=(278, 278, 0),
+                        background=(0.02, 0.02, 0.03), seed=11)
+    cam = rl.Camera(p)
+    frames, stats = {}, {}
+    try:
+        for v in (0, 2):  # 0: default (wave-scheduled, variant 4 for scenes with media), 2: nested loops
+            rl.api.set_rtiow_variant(v)
+            st = {}
+            frames[v] = cam.render(world, stats=st).data
+            stats[v] = st
+            buf = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+            cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            ts = rl.api.render_status(world)
+            assert np.array_equal(buf.cpu().numpy(), frames[v]) and ts["rays"] == st["rays"], v
+    finally:
+        rl.api.set_rtiow_variant(0)
+    assert np.array_equal(frames[0], frames[2])
+    for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
+        assert stats[0][k] == stats[2][k], (k, stats[0][k], stats[2][k])
+    if spp == 6:
+        cs = {}
+        cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+        assert cs["rays"] == stats[0]["rays"] and cs["rng_words"] == stats[0]["rng_words"]
+        assert np.abs(frames[0] - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
