@@ -1071,7 +1071,7 @@ rl_scene *rl_rtc_scene_create(const rl_rtc_scene_desc *desc) {
     set_err(RL_E_UNSUPPORTED, "max_reflection_depth above " + std::to_string(RTC_MAX_PENDING - 1) + " is not supported by the device kernel");
     return nullptr;
   }
-  if (!H->rc.needs_full) build_rtc_guards(H->rc, H->guards);
+  build_rtc_guards(H->rc, H->guards);  // both kernels walk them (the full kernel with the unbounded line test)
   std::shared_ptr<const HostRtc> Hc = H;
   std::vector<rl_scene *> reps;
   for (int g = 0; g < (int)g_ctx.size(); g++) {

@@ -104,6 +104,17 @@ __device__ inline void rtc_local_ray(const RtcParams &P, const DevOp *ops, uint3
   }
 }
 
+// guard_reject32 (rl_rtc_kernel.h) without a parameter range: true only when the whole LINE certainly misses the box
+__device__ __forceinline__ bool guard_reject32_line(const float *b, const RtcAux32 &ra) {
+  float t0x = fmaf(b[0], ra.invx, -ra.oix), t1x = fmaf(b[1], ra.invx, -ra.oix);
+  float t0y = fmaf(b[2], ra.invy, -ra.oiy), t1y = fmaf(b[3], ra.invy, -ra.oiy);
+  float t0z = fmaf(b[4], ra.invz, -ra.oiz), t1z = fmaf(b[5], ra.invz, -ra.oiz);
+  float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+  float thresh = fmaf(fabsf(tmin) + fabsf(tmax), 4.76837158203125e-07f, ra.slack);  // 8u(|tmin|+|tmax|) + slack
+  return (tmin - tmax) > thresh;                                                     // false for NaN / inf arithmetic
+}
+
 // World::intersect (world.rs:46-55) into list[0..n): evaluation order, CSG-filtered, normals in world space, sorted by t
 __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp *ops, const DevTri *tris, D3 wo, D3 wd, Ent *list,
                                             RtcFullCounters &cnt, unsigned long long mult) {
@@ -119,23 +130,43 @@ __device__ inline uint32_t rtc_intersect_all(const RtcFullParams &F, const DevOp
     if (code == ROP_END) break;
     if (code == ROP_TRIS) {
       uint32_t first = op.a, count = op.b;
-      for (uint32_t k = 0; k < count; k++) {
-        const DevTri &t = tris[first + k];
-        cnt.tris += mult;
+      auto test_triangle = [&](uint32_t ti) {  // triangle.rs:63-101
+        const DevTri &t = tris[ti];
         D3 e1 = ld3(t.e1), e2 = ld3(t.e2);
         D3 dir_cross_e2 = cross(d, e2);
         double det = dot(e1, dir_cross_e2);
-        if (fabs(det) < 1e-8) continue;
+        if (fabs(det) < 1e-8) return;
         double f = 1.0 / det;
         D3 p1_to_origin = o - ld3(t.p1);
         double u = f * dot(p1_to_origin, dir_cross_e2);
-        if (!(0.0 <= u && u <= 1.0)) continue;
+        if (!(0.0 <= u && u <= 1.0)) return;
         D3 origin_cross_e1 = cross(p1_to_origin, e1);
         double v = f * dot(d, origin_cross_e1);
-        if (v < 0.0 || (u + v) > 1.0) continue;
+        if (v < 0.0 || (u + v) > 1.0) return;
         double tt = f * dot(e2, origin_cross_e1);
         D3 nn = t.smooth ? nrm_or_flag((ld3(t.n2) * u + ld3(t.n3) * v) + ld3(t.n1) * (1.0 - u - v), cnt) : ld3(t.n1);
-        ent_push(list, n, tt, first + k, cur_enter, nn, cnt);
+        ent_push(list, n, tt, ti, cur_enter, nn, cnt);
+      };
+      cnt.tris += mult * count;  // the reference tests every triangle of the group (group.rs has no acceleration structure)
+      if (P.guards && op.skip != 0u) {
+        // reject-only box tree over the range (rl_render.hip build_rtc_guards; leaves in triangle order): a triangle is skipped only
+        // when the ray's LINE certainly misses its padded box — every intersection, of either sign of t, is still collected in order
+        const RtcAux32 ax = rtc_aux32(o, d);
+        uint32_t g = op.skip - 1u;
+        const uint32_t gend = P.guards[g].skip;
+        while (g < gend) {
+          const RtcGuard &nd = P.guards[g];
+          const float bx[6] = {nd.box[0], nd.box[1], nd.box[2], nd.box[3], nd.box[4], nd.box[5]};
+          const uint32_t nskip = nd.skip, ntri = nd.tri;
+          if (guard_reject32_line(bx, ax)) g = nskip;
+          else if (ntri == NONE) g++;
+          else {
+            test_triangle(ntri);
+            g = nskip;
+          }
+        }
+      } else {
+        for (uint32_t k = 0; k < count; k++) test_triangle(first + k);
       }
       pc++;
       continue;

@@ -119,3 +119,22 @@ def test_rtc_reflection_depth_cap_is_loud_and_depth_7_matches_oracle(rl, oracle)
     with pytest.raises(api.RLError) as e:
         build(8).render(1)
     assert "max_reflection_depth" in str(e.value), str(e.value)
+
+
+def test_rtc_reflective_mesh_through_the_full_kernel_walks_the_guard_tree(rl, oracle, golden):
+    """The teapot of tests/ray_tracer.rs:242-275 with a reflective, slightly transparent material: a triangle mesh through
+    World::color_at's full recursion.  The full kernel walks the reject-only box tree over each triangle range with an UNBOUNDED line
+    test (it needs every intersection, of either sign of t); counters and colours must equal the oracle's every-triangle loop."""
+    import ctypes as C
+    api = rl.api
+    world = rl.RtcWorld.test_obj_scene(golden("teapot-low.obj"), 120, 80)
+    desc = api.RtcSceneDesc.from_address(world.desc)
+    mats = np.frombuffer((C.c_char * (desc.n_materials * api.RTC_MATERIAL.itemsize)).from_address(desc.materials), dtype=api.RTC_MATERIAL)
+    mats["reflectivity"], mats["transparency"], mats["refractive_index"] = 0.35, 0.2, 1.3
+    gs, cs = {}, {}
+    img = world.render(1, stats=gs)
+    cpu = oracle.rtc_render(world.desc, world.camera, aa=1, stats=cs)
+    for k in COUNTERS:
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    assert gs["rays"] > 3 * 120 * 80 and gs["planar_tests"] > 200 * gs["rays"] // 2  # secondary rays, every triangle counted
+    assert np.abs(img - cpu).max() <= 1e-10
