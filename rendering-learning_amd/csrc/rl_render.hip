@@ -796,6 +796,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       // 64 >> RL_THIN_SHIFT pixels per wave, RL_PRIO=<permille> raises the issue priority of the waves that hold them.  Measured on the
       // emulated 1/8 shard: 271 - 283 ms against 279 at best, slower when more than ~1 % of the tiles are thinned: the longest sample
       // chain's time is per-ray LATENCY (9.6 us for a pixel alone on the GPU, tools/lone_ray.py), which neither shortens
+#ifdef RL_EXPERIMENTAL
       double permille = 0.0;
       if (const char *e = std::getenv("RL_THIN")) permille = std::atof(e);
       P.thin_tiles = (uint32_t)((double)ntiles * permille / 1000.0);
@@ -804,6 +805,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       if (const char *e = std::getenv("RL_THIN_SHIFT")) P.thin_shift = (uint32_t)std::min(6, std::max(1, std::atoi(e)));
       uint64_t total = slots + (((uint64_t)P.thin_tiles * 64u) << P.thin_shift);
       if (total >= 0xFFFF0000ull) P.thin_tiles = 0;
+#endif
     }
     rc = launch_variant();
   }

@@ -29,6 +29,13 @@ namespace rl {
 // ST_SHADE2 (fast traversal only): the specular half of SHADE — Metal and Dielectric hits — so that the many Lambertian / miss lanes
 // do not walk through normalize(), Schlick and refract() code they never need
 enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6, ST_PARK = 7 };
+// The latency modes of DESIGN.md §6 (RL_THIN: thin tiles, RL_PRIO: wave priority) — measured, no gain — are compiled into the
+// experimental library only (make exp); the product kernel carries none of their code.
+#ifdef RL_EXPERIMENTAL
+static constexpr bool LATENCY_MODES = true;
+#else
+static constexpr bool LATENCY_MODES = false;
+#endif
 
 // two-block ChaCha ring in LDS: 16 u64 slots per lane, slot-major ([slot][lane]) => conflict-free
 template <int NT>
@@ -561,7 +568,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     int n_gen = __popcll(__ballot(state == ST_GEN));
     int n_leaf = __popcll(__ballot(state == ST_LEAF));
     int n_shade2 = SPLIT_SHADE && LDS_SCENE == 4 ? __popcll(__ballot(state == ST_SHADE2)) : 0;
-    if (LDS_SCENE == 4 && P.thin_tiles != 0u) {  // parked lanes wake up when no lane of the wave holds a thin pixel any more
+    if (LATENCY_MODES && LDS_SCENE == 4 && P.thin_tiles != 0u) {  // parked lanes wake up when no lane of the wave holds a thin pixel any more
       if (__ballot(state == ST_PARK) != 0ull && __ballot(have_pixel && thin_pix) == 0ull) {
         if (state == ST_PARK) state = ST_GEN;
         n_gen = __popcll(__ballot(state == ST_GEN));
@@ -719,7 +726,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           // parks until its wave's thin pixels are done.  A wave then serialises 16 sample chains instead of 64: the longest chains
           // of the frame (the shard's critical path) see a quarter of the state divergence.
           const uint32_t sh = P.thin_shift;  // a thin tile's 64 pixels go out over 1 << sh wave-claims, 64 >> sh pixels each
-          const uint32_t thin_slots = LDS_SCENE == 4 ? (P.thin_tiles * 64u) << sh : 0u;
+          const uint32_t thin_slots = LATENCY_MODES && LDS_SCENE == 4 ? (P.thin_tiles * 64u) << sh : 0u;
           thin_pix = false;
           bool parked = false;
           if (slot < thin_slots) {
@@ -727,8 +734,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             parked = (l & ((1u << sh) - 1u)) != 0u;
             thin_pix = !parked;
             slot = (slot >> (6u + sh)) * 64u + (sub >> 6) * (64u >> sh) + (l >> sh);
-          } else {
-            slot -= thin_slots - P.thin_tiles * 64u;
+          } else if (LATENCY_MODES) {
+            slot -= thin_slots - (LDS_SCENE == 4 ? P.thin_tiles * 64u : 0u);
             if (LDS_SCENE == 4 && P.prio_tiles != 0u) thin_pix = (slot >> 6) < P.prio_tiles;
           }
           if (parked) {
@@ -792,7 +799,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
           }
         }
       }
-      if (LDS_SCENE == 4 && P.prio_tiles != 0u) {  // A/B: issue priority for the waves that hold the frame's longest sample chains
+      if (LATENCY_MODES && LDS_SCENE == 4 && P.prio_tiles != 0u) {  // A/B: issue priority for the waves that hold the frame's longest sample chains
         if (__ballot(have_pixel && thin_pix) != 0ull) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
       }
