@@ -858,6 +858,139 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
 }
 
 // Not part of the ABI (tests / tools only): force an RTIOW kernel variant (0 auto, 1 nested-loop, 2 general, 512/768/1024 wave).
+// Host-only self-check of the traversal structures a scene compiles to (no device needed: tests/test_host_structures.py runs it in the
+// CPU tier).  out[16]: [0] bit 0: sphere fast tree built, bit 1: general fast structure built; general structure: [1] items,
+// [2] binary nodes, [3] four-wide nodes, [4] leaf entries reached from the root, [5] items reached more than once, [6] items never
+// reached, [7] boxes that fail to contain what lies below them (child boxes of inner children; the vertices / swept spheres of
+// world-space items), [8] depth of the four-wide tree; sphere tree: [9] inner nodes, [10] leaves reached, [11] spheres reached more
+// than once or never, [12] boxes that fail to contain the swept sphere below, [13] depth.  Returns RL_OK or the compile error.
+int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long *out16) {
+  if (!desc || !out16) return set_err(RL_E_INVALID, "bad argument");
+  std::shared_ptr<const HostRtiow> H;
+  int rc = build_host_rtiow(desc, H);
+  if (rc != RL_OK) return rc;
+  for (int i = 0; i < 16; i++) out16[i] = 0;
+  const FastGeneral &fg = H->fg;
+  if (H->fast_root != FAST_NONE) out16[0] |= 1ull;
+  if (fg.ok) out16[0] |= 2ull;
+  if (fg.ok) {
+    out16[1] = fg.items.size(), out16[2] = fg.nodes.size(), out16[3] = fg.qnodes.size();
+    std::vector<uint32_t> seen(fg.items.size(), 0u);
+    struct Frame {
+      uint32_t e;
+      float box[6];
+      bool has_box;
+      unsigned depth;
+    };
+    std::vector<Frame> st;
+    if (fg.qroot != NONE) st.push_back(Frame{fg.qroot, {0, 0, 0, 0, 0, 0}, false, 1u});
+    auto inside = [](const float *outer, const double *lo, const double *hi) {
+      for (int ax = 0; ax < 3; ax++)
+        if (!((double)outer[2 * ax] <= lo[ax] && hi[ax] <= (double)outer[2 * ax + 1])) return false;
+      return true;
+    };
+    while (!st.empty()) {
+      Frame f = st.back();
+      st.pop_back();
+      out16[8] = std::max<unsigned long long>(out16[8], f.depth);
+      if (f.e & FASTG_LEAF) {
+        const uint32_t item = f.e & ~FASTG_LEAF;
+        out16[4]++;
+        if (item >= seen.size()) {
+          out16[7]++;
+          continue;
+        }
+        seen[item]++;
+        const FastItem &it = fg.items[item];
+        if (f.has_box && it.chain == NONE) {  // world-space item: its geometry must lie inside the leaf's box
+          double lo[3], hi[3];
+          if (it.kind == 0) {
+            const rl_sphere &sp = desc->spheres[it.payload & SPH_INDEX];
+            for (int ax = 0; ax < 3; ax++) {
+              double c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
+              lo[ax] = std::fmin(sp.center0[ax], c1) - std::fabs(sp.radius), hi[ax] = std::fmax(sp.center0[ax], c1) + std::fabs(sp.radius);
+            }
+          } else {
+            const rl_planar &pl = desc->planars[it.payload];
+            for (int ax = 0; ax < 3; ax++) {
+              double v[4] = {pl.q[ax], pl.q[ax] + pl.u[ax], pl.q[ax] + pl.v[ax], pl.kind == RL_PLANAR_QUAD ? pl.q[ax] + pl.u[ax] + pl.v[ax] : pl.q[ax]};
+              lo[ax] = std::fmin(std::fmin(v[0], v[1]), std::fmin(v[2], v[3])), hi[ax] = std::fmax(std::fmax(v[0], v[1]), std::fmax(v[2], v[3]));
+            }
+          }
+          if (!inside(f.box, lo, hi)) out16[7]++;
+        }
+        continue;
+      }
+      if (f.e >= fg.qnodes.size()) {
+        out16[7]++;
+        continue;
+      }
+      const FastNodeQ &q = fg.qnodes[f.e];
+      double ulo[3] = {INFINITY, INFINITY, INFINITY}, uhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int k = 0; k < 4; k++) {
+        if (q.child[k] == NONE) continue;
+        Frame c{q.child[k], {q.lo[0][k], q.hi[0][k], q.lo[1][k], q.hi[1][k], q.lo[2][k], q.hi[2][k]}, true, f.depth + 1u};
+        for (int ax = 0; ax < 3; ax++) ulo[ax] = std::fmin(ulo[ax], (double)c.box[2 * ax]), uhi[ax] = std::fmax(uhi[ax], (double)c.box[2 * ax + 1]);
+        st.push_back(c);
+      }
+      if (f.has_box && !inside(f.box, ulo, uhi)) out16[7]++;  // a node's box (held by its parent) contains its children's boxes
+    }
+    for (uint32_t c : seen) out16[5] += c > 1u ? 1u : 0u, out16[6] += c == 0u ? 1u : 0u;
+  }
+  if (H->fast_root != FAST_NONE) {
+    const std::vector<FastNode> &nodes = H->fast_nodes;
+    const uint32_t n_inner = (uint32_t)nodes.size(), n_sph = desc->n_spheres;
+    out16[9] = n_inner;
+    std::vector<uint32_t> seen(n_sph, 0u);
+    struct Frame {
+      uint32_t e;
+      float box[6];
+      bool has_box;
+      unsigned depth;
+    };
+    std::vector<Frame> st;
+    st.push_back(Frame{H->fast_root, {0, 0, 0, 0, 0, 0}, false, 1u});
+    while (!st.empty()) {
+      Frame f = st.back();
+      st.pop_back();
+      out16[13] = std::max<unsigned long long>(out16[13], f.depth);
+      if (f.e >= n_inner) {
+        const uint32_t si = f.e - n_inner;
+        out16[10]++;
+        if (si >= n_sph) {
+          out16[12]++;
+          continue;
+        }
+        seen[si]++;
+        if (f.has_box) {
+          const rl_sphere &sp = desc->spheres[si];
+          for (int ax = 0; ax < 3; ax++) {
+            double c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
+            double lo = std::fmin(sp.center0[ax], c1) - std::fabs(sp.radius), hi = std::fmax(sp.center0[ax], c1) + std::fabs(sp.radius);
+            if (!((double)f.box[2 * ax] <= lo && hi <= (double)f.box[2 * ax + 1])) {
+              out16[12]++;
+              break;
+            }
+          }
+        }
+        continue;
+      }
+      const FastNode &nd = nodes[f.e];
+      for (int k = 0; k < 2; k++) {
+        Frame c{k == 0 ? (nd.child & 0xFFFFu) : (nd.child >> 16), {nd.box[k][0], nd.box[k][1], nd.box[k][2], nd.box[k][3], nd.box[k][4], nd.box[k][5]}, true, f.depth + 1u};
+        if (f.has_box)
+          for (int ax = 0; ax < 3; ax++)
+            if (!(f.box[2 * ax] <= c.box[2 * ax] && c.box[2 * ax + 1] <= f.box[2 * ax + 1])) {
+              out16[12]++;
+              break;
+            }
+        st.push_back(c);
+      }
+    }
+    for (uint32_t c : seen) out16[11] += c != 1u ? 1u : 0u;
+  }
+  return RL_OK;
+}
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
 void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
