@@ -22,6 +22,7 @@
 #include "rl_rtiow_wave.h"
 #include "rl_rtiow_wave_general.h"
 #include "rl_rtiow_fastgen.h"
+#include "rl_rtiow_coop.h"
 #ifdef RL_EXPERIMENTAL  // the measured-and-lost restructurings: only in librl_render_exp.so, never in the product library
 #include "experimental/rl_rtiow_pool.h"
 #include "experimental/rl_rtiow_wave2.h"
@@ -61,6 +62,11 @@ int upload(const std::vector<T> &v, T **out) {
   HIP_TRY(hipMalloc((void **)out, bytes));
   if (!v.empty()) HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return RL_OK;
+}
+
+__global__ void iota_u32(uint32_t *out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
 }
 
 // Output stages
@@ -161,7 +167,7 @@ int rl_init(int device) {
   if (rc != RL_OK) return rc;
   if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
     std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : 0;
+    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : sv == "coop" ? 1033 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   if (const char *v = std::getenv("RL_FAST")) g_fast_traversal = std::string(v) != "0";
@@ -194,7 +200,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -374,6 +380,17 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
     }
     // the fast traversal structure of the timed (counter-free) kernel: ordered binary tree, reject-only boxes (rl_fast_bvh.cpp)
     if (!H->cops.empty() && !build_fast_bvh(*desc, rt, frame, H->fast_nodes, H->fast_root)) H->fast_nodes.clear(), H->fast_root = FAST_NONE;
+    if (H->fast_root != FAST_NONE) {  // the spheres' own (padded) leaf boxes, by sphere index: what the cooperative kernel scans
+      const uint32_t n_inner = (uint32_t)H->fast_nodes.size(), ns = (uint32_t)rt.spheres.size();
+      H->fast_leaf_boxes.assign((size_t)ns * 8, 0.0f);
+      for (uint32_t s = 0; s < ns; s++)  // a sphere the tree does not hold (n == 1: no node at all) is always a candidate
+        for (int k = 0; k < 3; k++) H->fast_leaf_boxes[(size_t)s * 8 + 2 * k] = -3.0e38f, H->fast_leaf_boxes[(size_t)s * 8 + 2 * k + 1] = 3.0e38f;
+      for (const FastNode &nd : H->fast_nodes)
+        for (int k = 0; k < 2; k++) {
+          const uint32_t e = k == 0 ? (nd.child & 0xFFFFu) : (nd.child >> 16);
+          if (e >= n_inner && e - n_inner < ns) std::memcpy(&H->fast_leaf_boxes[(size_t)(e - n_inner) * 8], nd.box[k], 6 * sizeof(float));
+        }
+    }
   } else if (rt.ops.size() < (1u << 31)) {
     // general scenes (planars, instances, image / noise textures): world-space tree over the primitive occurrences
     if (!build_fast_general(*desc, rt, H->fg)) H->fg = FastGeneral{};
@@ -395,7 +412,7 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (rc = scene_common(s)) ||
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
-      (H->fast_root != FAST_NONE && (rc = upload(H->fast_nodes, &s->d_fast_nodes))) ||
+      (H->fast_root != FAST_NONE && ((rc = upload(H->fast_nodes, &s->d_fast_nodes)) || (rc = upload(H->fast_leaf_boxes, &s->d_fast_leaf_boxes)))) ||
       (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
     destroy_one(s);
     return nullptr;
@@ -649,6 +666,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   const bool fits_fast = fits_compact && H.fast_root != FAST_NONE && (!want_stats || g_fast_debug_stats) && (size_t)16 * 1024 * sizeof(unsigned long long) + fast_bytes <= g_lds_max &&
                          g_fast_traversal;
   if (variant == 1029 && (general || !fits_fast)) variant = 0;
+  if (variant == 1033 && (general || !fits_fast || want_stats)) variant = 0;  // cooperative kernel: the fast structure's scenes, counter-free renders
   if (variant == 1027 && (general || !fits_compact)) variant = 0;
   if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
@@ -660,6 +678,23 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
     variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
   }
+  auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
+    constexpr int NW = 4;
+    CoopParams C{};
+    C.pixels = d_pixels, C.n_pixels = n_pixels, C.leaf_boxes = scene->d_fast_leaf_boxes;
+    C.counter = (uint32_t *)(scene->d_scratch + 256);
+    C.max_cand = 128;
+    HIP_TRY(hipMemsetAsync(C.counter, 0, 4, stream));
+    size_t lds = (size_t)8 * NW * 64 * sizeof(unsigned long long) + (size_t)NW * C.max_cand * sizeof(uint32_t);
+    uint32_t blocks = (n_pixels + NW - 1) / NW;
+    uint32_t cap = (uint32_t)g_cus * (16 / NW);  // 4 waves per SIMD at 128 VGPRs
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) return RL_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rtiow_coop_kernel<NW>, dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+    HIP_TRY(hipGetLastError());
+    return RL_OK;
+  };
   auto launch_variant = [&]() -> int {
     int rc;
 #define RL_LAUNCH_WAVE(NT)                                                                                              \
@@ -730,6 +765,17 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp);
       rc = want_stats ? launch(rtiow_wave_kernel<NT, 2, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 2, false>, NT, rb, false);
+    } else if (variant == 1033) {  // A/B: EVERY pixel through the cooperative one-wave-per-pixel kernel (rl_rtiow_coop.h)
+      rl_scene *ms = const_cast<rl_scene *>(scene);
+      const size_t npix = (size_t)nrows * W;
+      if (ms->coop_pixels_cap < npix) {
+        hipFree(ms->d_coop_pixels);
+        ms->d_coop_pixels = nullptr, ms->coop_pixels_cap = 0;
+        HIP_TRY(hipMalloc((void **)&ms->d_coop_pixels, npix * sizeof(uint32_t)));
+        ms->coop_pixels_cap = npix;
+      }
+      hipLaunchKernelGGL(iota_u32, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, ms->d_coop_pixels, (uint32_t)npix);
+      rc = launch_coop(ms->d_coop_pixels, (uint32_t)npix);
     } else if (variant == 1029) {  // 4 waves per SIMD: rings + fast traversal nodes in LDS, spheres read from L2; never a counting render
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;

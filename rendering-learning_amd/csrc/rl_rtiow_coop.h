@@ -1,0 +1,271 @@
+// Cooperative latency kernel for the per-pixel sample chain: ONE WAVE PER PIXEL.
+//
+// The samples of a pixel are sequential in the reference (camera.rs:161-174: sample n + 1 starts at the ChaCha word position sample n
+// stopped at), so when a shard has about as many pixels as the GPU has lanes, the frame time is the time of its longest chains — and a
+// chain advances at the latency of one ray through the state machine of rl_rtiow_wave.h (9.6 us for a lone lane, 22.6 us inside a full
+// wave).  This kernel runs the most expensive pixels of such a shard differently: all 64 lanes of a wave carry the SAME pixel (same RNG
+// stream, same arithmetic, redundantly — there is no divergence and no scheduler), and the one thing that can be spread over the lanes
+// is: World::hit.  Each lane tests the reject-only binary32 leaf boxes of eight of the scene's spheres (the boxes of rl_fast_bvh.cpp,
+// same certain-miss test as the fast traversal), the candidates are compacted through LDS, one lane per candidate evaluates the
+// reference's Sphere::hit, and a wave reduction picks the closest root.  Order-sensitive rays (two roots within the tie band, a
+// grazing / pole hit of the winner, a ray outside the binary32 range) are re-traced by fast_slow_trace, the reference's own fold,
+// exactly as in the fast traversal — so the pixels are the bits the other kernels produce.
+#pragma once
+#include "rl_rtiow_wave.h"
+
+namespace rl {
+
+struct CoopParams {
+  const uint32_t *pixels;   // [n_pixels] virtual pixel index pr * W + px (pr = row within the shard), most expensive first
+  uint32_t n_pixels;
+  const uint32_t *n_pixels_dev;  // when not null: the length of the list, written by an earlier kernel on the same stream
+  const float *leaf_boxes;  // [n_spheres][8]: x.min, x.max, y.min, y.max, z.min, z.max, 0, 0 (padded, rounded outwards)
+  uint32_t *counter;        // work counter (zeroed before the launch)
+  uint32_t max_cand;        // capacity of the per-wave candidate list in LDS
+};
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;  // NaN never enters (lanes without a hit hold +inf)
+  }
+  return v;
+}
+
+// The body: NT threads = NT / 64 waves, each wave claims pixels of C.pixels until the list is exhausted.
+// LDS: [8][NT] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NT / 64][max_cand] u32 candidate lists.
+template <int NT>
+__device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const CoopParams &C, unsigned char *smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long *s_rng = (unsigned long long *)smem;  // [8][NT]
+  uint32_t *s_cand = (uint32_t *)(smem + (size_t)8 * NT * sizeof(unsigned long long)) + (size_t)wave * C.max_cand;
+  const DevOp *ops = P.ops;
+  const DevSphere *spheres = P.spheres;
+  RngCtx<NT> rc{P.key, s_rng, tid};
+  const rl_rtiow_camera &cam = P.cam;
+  const uint32_t W = cam.image_width;
+  const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
+  const D3 p00 = ld3(cam.pixel_00), du = ld3(cam.pixel_du), dv = ld3(cam.pixel_dv);
+  const D3 lookfrom = ld3(cam.lookfrom), ddu = ld3(cam.defocus_disk_u), ddv = ld3(cam.defocus_disk_v);
+  const D3 background = ld3(cam.background);
+  const double INF = __longlong_as_double(0x7FF0000000000000ll);
+  const float FINF = __int_as_float(0x7F800000);
+  const uint32_t n_sph = P.n_spheres;
+  uint32_t c_rays = 0, c_flag = 0, c_slow = 0;
+  const uint32_t n_pixels = C.n_pixels_dev ? *C.n_pixels_dev : C.n_pixels;  // the list's length may have been decided on the device
+
+  for (;;) {
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(C.counter, 1u);
+    idx = __shfl(idx, 0, 64);
+    if (idx >= n_pixels) break;
+    const uint32_t pix = C.pixels[idx];
+    const uint32_t x = pix % W, r = pix / W;
+    const uint32_t y = P.row_first + r * P.row_step;
+    Rng rng{0ull, 0u, 0xFFFFFFFFu};
+    D3 sum = d3(0.0, 0.0, 0.0);
+    if (P.resume) {  // continue where the previous launch stopped: same sums, same ChaCha word position
+      const double *inp = P.out + (size_t)pix * 3;
+      sum = d3(inp[0], inp[1], inp[2]);
+      rng.pos = P.pos_state[pix];
+    }
+    for (uint32_t n = P.sample_begin; n < P.sample_end; n++) {
+      uint64_t sample_index = (uint64_t)n + P.first_sample;
+      rng.stream = sample_index * WH + (uint64_t)x * (uint64_t)W + (uint64_t)y;  // camera.rs:167-169 (x*W, sic)
+      rng.buf_ctr = 0xFFFFFFFFu;
+      D3 pixel_center = (p00 + du * (double)x) + dv * (double)y;
+      double sx = -0.5 + rc.gen_f64(rng);
+      double sy = -0.5 + rc.gen_f64(rng);
+      D3 pixel_sample = pixel_center + (du * sx + dv * sy);
+      D3 o;
+      if (cam.defocus_angle <= 0.0) o = lookfrom;
+      else {
+        double a, b;
+        rc.unit_disc(rng, a, b);
+        o = (lookfrom + ddu * a) + ddv * b;
+      }
+      D3 d = pixel_sample - o;
+      double time = rc.gen_f64(rng);
+      D3 thr = d3(1.0, 1.0, 1.0);
+      D3 color = d3(0.0, 0.0, 0.0);
+      for (uint32_t depth = cam.max_depth; depth > 0; depth--) {
+        c_rays++;
+        // ---- world.hit(r, [1e-10, inf]), cooperatively
+        double closest = INF;
+        uint32_t hit_prim = NONE;
+        const RayAux32 ra32 = ray_aux32_direct(o, d);
+        bool amb = !(ra32.slack < FINF);  // outside the binary32 filter's range: the reference's order
+        if (!amb) {
+          // (1) every lane: the leaf boxes of spheres lane, lane + 64, ... (certain-miss test of the fast traversal, closest = +inf)
+          uint32_t ncand = 0;
+          __builtin_amdgcn_wave_barrier();  // the previous ray's candidate list is no longer read
+          for (uint32_t base = 0; base < n_sph; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            bool cand = false;
+            if (i < n_sph) {
+              const Float4 b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
+              float t0x = fmaf(b0.x, ra32.invx, -ra32.oix), t1x = fmaf(b0.y, ra32.invx, -ra32.oix);
+              float t0y = fmaf(b0.z, ra32.invy, -ra32.oiy), t1y = fmaf(b0.w, ra32.invy, -ra32.oiy);
+              float t0z = fmaf(b1.x, ra32.invz, -ra32.oiz), t1z = fmaf(b1.y, ra32.invz, -ra32.oiz);
+              float tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
+              float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+              float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
+              cand = !((tmax - tmin) < -thresh);                                           // NaN arithmetic: candidate
+            }
+            const unsigned long long mask = __ballot(cand);
+            if (cand) {
+              const uint32_t slot = ncand + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+              if (slot < C.max_cand) s_cand[slot] = i;
+            }
+            ncand += (uint32_t)__popcll(mask);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the candidate list is read by other lanes of this wave
+          __builtin_amdgcn_wave_barrier();
+          if (ncand > C.max_cand) amb = true;  // more candidates than the list holds: the reference's fold
+          else {
+            // (2) one lane per candidate: Sphere::hit (sphere.rs:32-75) with ray_t = [1e-10, +inf): same arithmetic, same roots as
+            // fast_sphere_hit; (3) wave reduction: closest root, runner-up and the widest tie band seen
+            double second = INF, band_all = 0.0;
+            bool sens_w = false;
+            for (uint32_t c0 = 0; c0 < ncand; c0 += 64u) {
+              const uint32_t k = c0 + (uint32_t)lane;
+              double t_k = INF, band_k = 0.0;
+              uint32_t payload_k = NONE;
+              bool sens_k = false;
+              if (k < ncand) {
+                const uint32_t si = s_cand[k];
+                const uint32_t payload = si | (((P.movbits[si >> 5] >> (si & 31u)) & 1u) ? SPH_MOVING : 0u);
+                const DevSphere &s = spheres[si];
+                D3 c0v = ld3(s.c0);
+                D3 center = (payload & SPH_MOVING) ? c0v + ld3(s.dc) * time : c0v;
+                D3 oc = o - center;
+                double a = len2(d);
+                double half_b = dot(oc, d);
+                double c = len2(oc) - s.r2;
+                double disc = half_b * half_b - a * c;
+                if (!(disc < 0.0)) {
+                  double sq = sqrt(disc);
+                  double r_l = (-half_b - sq) / a;
+                  double r_u = (-half_b + sq) / a;
+                  double t = INF;
+                  bool ok = true;
+                  if (1e-10 <= r_l) t = r_l;
+                  else if (1e-10 <= r_u) t = r_u;
+                  else ok = false;
+                  if (ok) {
+                    t_k = t, payload_k = payload;
+                    band_k = fast_tie_band(fabs(r_l) + fabs(r_u), ra32.oimax());
+                    sens_k = fast_hit_is_order_sensitive(oc, d, t, s.r2 * s.inv_r, half_b, sq, r_l, r_u, ra32.oimax());
+                  }
+                }
+              }
+              const double t_min = wave_min_f64(t_k);
+              const unsigned long long hit_mask = __ballot(payload_k != NONE);
+              if (hit_mask == 0ull) continue;
+              const unsigned long long win_mask = __ballot(payload_k != NONE && t_k == t_min);
+              const int wl = __ffsll((long long)win_mask) - 1;
+              const double t_2nd = wave_min_f64(lane == wl ? INF : t_k);
+              band_all = fmax(band_all, -wave_min_f64(-band_k));
+              if (win_mask != 0ull && t_min < closest) {  // (a NaN root never wins: win_mask is empty then, and the ray is re-traced below)
+                second = fmin(fmin(second, closest), t_2nd);
+                closest = t_min;
+                hit_prim = __shfl(payload_k, wl, 64);
+                sens_w = __shfl(sens_k ? 1 : 0, wl, 64) != 0;
+              } else second = fmin(second, t_min);
+              if (win_mask == 0ull) amb = true;  // NaN arithmetic in a root: the reference's fold decides
+            }
+            // order-sensitive: the winner grazes / sits next to an axis pole, or the runner-up is within the tie band (exact ties go
+            // to the LAST sphere in the reference's order)
+            if (hit_prim != NONE && (sens_w || !(second - closest > band_all))) amb = true;
+          }
+        }
+        if (amb) {  // rare: the reference's own fold (uniform: every lane holds the same ray)
+          c_flag += fast_slow_trace(ops, spheres, o, d, time, closest, hit_prim);
+          c_slow++;
+        }
+        if (hit_prim == NONE) {
+          color = color + thr * background;
+          break;
+        }
+        // ---- the HitRecord of the winner and Material::scatter, as in rl_rtiow_kernel.h (same arithmetic as at test time)
+        uint32_t si = hit_prim & SPH_INDEX;
+        const DevSphere &s = spheres[si];
+        D3 c0v = ld3(s.c0);
+        D3 center = (hit_prim & SPH_MOVING) ? c0v + ld3(s.dc) * time : c0v;
+        D3 p = o + d * closest;
+        D3 outward = (p - center) * s.inv_r;
+        bool front = dot(d, outward) <= 0.0;
+        D3 normal = front ? outward : -outward;
+        const DevMaterial &m = P.materials[P.sphere_material[si]];
+        uint32_t kind = m.kind;
+        D3 nd;
+        if (kind == RL_MAT_LAMBERTIAN) {
+          D3 dir = normal + rc.unit_sphere(rng);
+          bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
+          nd = near_zero ? normal : dir;
+          thr = thr * texture_value(P, m.texture, 0.0, 0.0, p);
+        } else if (kind == RL_MAT_METAL) {
+          D3 reflected = d - normal * (2.0 * dot(d, normal));
+          nd = normalize(reflected) + rc.unit_sphere(rng) * m.fuzz;
+          if (!(dot(nd, normal) > 0.0)) break;
+          thr = thr * ld3(m.albedo);
+        } else if (kind == RL_MAT_DIELECTRIC) {
+          double ri = front ? 1.0 / m.ior : m.ior;
+          double m2 = len2(d);
+          D3 ud;
+          if (approx_eq_eps(m2, 0.0, 1e-16)) {
+            c_flag++;
+            ud = d;
+          } else
+            ud = normalize(d);
+          double cos_theta = fmin(dot(-ud, normal), 1.0);
+          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+          bool reflect = ri * sin_theta > 1.0;
+          if (!reflect) {
+            double q = (1.0 - ri) / (1.0 + ri);
+            double r0 = q * q;
+            double xx = 1.0 - cos_theta;
+            double x2 = xx * xx;
+            double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
+            reflect = refl > rc.gen_f64(rng);
+          }
+          if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
+          else {
+            D3 perp = (ud + normal * cos_theta) * ri;
+            D3 par = normal * (-sqrt(fabs(1.0 - len2(perp))));
+            nd = perp + par;
+          }
+        } else if (kind == RL_MAT_DIFFUSE_LIGHT) {
+          color = color + thr * texture_value(P, m.texture, 0.0, 0.0, p);
+          break;
+        } else {
+          break;
+        }
+        o = p;
+        d = nd;
+      }
+      sum = sum + color;
+    }
+    if (lane == 0) {
+      double *outp = P.out + (size_t)pix * 3;
+      outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+      if (P.pos_state) P.pos_state[pix] = rng.pos;
+    }
+  }
+  // every lane of a wave counted the same rays: lane 0 reports
+  if (lane == 0) {
+    if (c_rays) atomicAdd(&P.stats[0], (unsigned long long)c_rays);
+    if (c_flag) atomicAdd(&P.stats[6], (unsigned long long)c_flag);
+    if (c_slow) atomicAdd(&P.stats[7], (unsigned long long)c_slow);
+  }
+}
+
+// stand-alone form (A/B and tests, RL_RTIOW_KERNEL=coop): every pixel of the list through the cooperative body
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  rtiow_coop_body<NW * 64>(P, C, smem);
+}
+
+}  // namespace rl

@@ -28,6 +28,7 @@ struct HostRtiow {
   uint32_t entry0 = 0, centry0 = 0;
   std::vector<FastNode> fast_nodes;  // fast traversal structure (rl_fast_bvh.cpp); fast_root == FAST_NONE: the scene does not qualify
   uint32_t fast_root = FAST_NONE;
+  std::vector<float> fast_leaf_boxes;  // [n_spheres][8]: each sphere's padded leaf box of the fast tree (rl_rtiow_coop.h)
   FastGeneral fg;  // fast traversal structure of a general scene (fg.ok == false: the scene does not qualify)
   // the guard boxes' padding is rigorous for ray origins within guard_reach of guard_center (rl_render.hip link_ops)
   double guard_center[3] = {0, 0, 0}, guard_reach = 0;
@@ -54,6 +55,9 @@ struct rl_scene {
   rl::CompactOp *d_cops = nullptr;
   uint32_t *d_movbits = nullptr;
   rl::FastNode *d_fast_nodes = nullptr;
+  float *d_fast_leaf_boxes = nullptr;
+  uint32_t *d_coop_pixels = nullptr;  // cooperative kernel: pixel list (scratch, grown on demand)
+  size_t coop_pixels_cap = 0;
   rl::FastNodeQ *d_fg_nodes = nullptr;
   rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_fg_spheres = nullptr;
