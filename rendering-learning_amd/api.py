@@ -250,6 +250,11 @@ def set_fast_traversal(on):
     render_lib().rl_debug_set_fast_traversal(int(bool(on)))
 
 
+def set_coop(on):
+    """Tests / tools: counter-free renders of SMALL frames of sphere scenes use the cooperative one-wave-per-pixel kernel unless switched off."""
+    render_lib().rl_debug_set_coop(int(bool(on)))
+
+
 def has_experimental():
     return bool(render_lib().rl_debug_has_experimental())
 

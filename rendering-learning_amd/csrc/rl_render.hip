@@ -41,6 +41,7 @@ int g_cus = 0;
 size_t g_lds_max = 65536;
 int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
 bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
+bool g_coop_small = true;  // small frames through the cooperative kernel (RL_COOP=0 disables; A/B only)
 unsigned long long g_last_slow_traces = 0;
 bool g_fast_debug_stats = false;  // tools only: counting renders run the fast kernel too (counters are then NOT the reference's)
 bool g_fast_traversal = true;  // counter-free renders of LDS-sized sphere scenes use the fast traversal (RL_FAST=0 disables; A/B only)
@@ -170,6 +171,7 @@ int rl_init(int device) {
     g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : sv == "coop" ? 1033 : 0;
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
+  if (const char *v = std::getenv("RL_COOP")) g_coop_small = std::string(v) != "0";
   if (const char *v = std::getenv("RL_FAST")) g_fast_traversal = std::string(v) != "0";
   g_ready = true;
   return RL_OK;
@@ -677,6 +679,10 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
     variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
+    // Small frames (at most ~12 pixels per wave the GPU can hold) are pure latency: every pixel's sample chain runs alone, and the
+    // cooperative one-wave-per-pixel kernel advances a chain in 3.9 us per ray instead of ~22 (rl_rtiow_coop.h).  Measured at 1024 spp:
+    // 2.2 k pixels 184 -> 32 ms, 9 k 248 -> 68, 20 k 267 -> 114, 37 k 264 -> 176, 90 k 291 -> 414 (tools/coop_check.py).
+    if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 12u) variant = 1033;
   }
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
     constexpr int NW = 4;
@@ -1039,6 +1045,7 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
 }
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
+void rl_debug_set_coop(int on) { g_coop_small = on != 0; }
 void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
 void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
 #ifdef RL_FASTG_VERIFY

@@ -22,12 +22,16 @@ def _frames(rl, cam, world, allow_degenerate=False):
         cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
         st = api.render_status(world, allow_degenerate=allow_degenerate)
         return buf.cpu().numpy(), st
-    fast, st = timed()
     try:
+        api.set_coop(False)  # small frames: the wave-scheduled fast kernel, not the cooperative one
+        fast, st = timed()
         api.set_fast_traversal(False)
         ref_order, st0 = timed()
     finally:
         api.set_fast_traversal(True)
+        api.set_coop(True)
+    auto, st_auto = timed()  # the library's own choice (the cooperative kernel for small frames of sphere scenes): the same bits
+    assert np.array_equal(auto, fast, equal_nan=True) and st_auto["rays"] == st["rays"] and st_auto["flagged"] == st["flagged"]
     assert st0["slow_traces"] == 0
     gs = {}
     counting = cam.render(world, stats=gs, allow_degenerate=allow_degenerate).data

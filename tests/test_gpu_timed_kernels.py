@@ -42,7 +42,7 @@ def _timed_vs_counting_vs_oracle(rl, oracle, world, p, tight=1e-9):
     return gs
 
 
-@pytest.mark.parametrize("variant", [0, 1025, 768, 1024, 1033])
+@pytest.mark.parametrize("variant", [0, 1025, 768, 1024, 1029, 1033])
 @pytest.mark.parametrize("spp", [6, 72])
 def test_timed_sphere_kernels_equal_counting_kernels_and_oracle(rl, oracle, variant, spp):
     """BASELINE configs[1] scene; spp = 72 takes the cost-sorted two-launch path at its real threshold (>= 64)."""
@@ -50,8 +50,8 @@ def test_timed_sphere_kernels_equal_counting_kernels_and_oracle(rl, oracle, vari
     p = world.params
     p.image_width, p.samples_per_pixel, p.max_depth = 128, spp, 50
     try:
-        # 0 = the default (counting: rtiow_wave_kernel<1024, 3, true>, timed: the fast traversal <1024, 4, false>);
-        # 1033 = every pixel through the cooperative one-wave-per-pixel kernel (rl_rtiow_coop.h; counter-free renders only)
+        # 0 = the default (counting: rtiow_wave_kernel<1024, 3, true>; timed: the cooperative kernel for a frame this small);
+        # 1029 = the fast traversal <1024, 4, false> (what larger frames use), 1033 = the cooperative one-wave-per-pixel kernel
         rl.api.set_rtiow_variant(variant)
         _timed_vs_counting_vs_oracle(rl, oracle, world, p)
     finally:

@@ -9,7 +9,8 @@ dev = torch.device("cuda", 0)
 L = rl.api.render_lib()
 L.rl_debug_pixel_rays.argtypes = [C.c_void_p, C.c_uint64]; L.rl_debug_pixel_rays_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-for width, aspect in ((1, 1.0), (8, 1.0), (32, 16.0 / 9.0), (128, 16.0 / 9.0)):
+sizes = [tuple(float(v) if i else int(v) for i, v in enumerate(a.split(':'))) for a in sys.argv[2:]] or [(1, 1.0), (8, 1.0), (32, 16.0 / 9.0), (128, 16.0 / 9.0)]
+for width, aspect in sizes:
     world = rl.World.bouncing_spheres(1)
     p = world.params
     p.image_width, p.aspect_ratio, p.samples_per_pixel, p.max_depth = width, aspect, spp, 50
