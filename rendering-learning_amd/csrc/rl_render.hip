@@ -681,7 +681,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
     // Small frames (at most ~12 pixels per wave the GPU can hold) are pure latency: every pixel's sample chain runs alone, and the
     // cooperative one-wave-per-pixel kernel advances a chain in 3.9 us per ray instead of ~22 (rl_rtiow_coop.h).  Measured at 1024 spp:
-    // 2.2 k pixels 184 -> 32 ms, 9 k 248 -> 68, 20 k 267 -> 114, 37 k 264 -> 176, 90 k 291 -> 414 (tools/coop_check.py).
+    // 2.2 k pixels 184 -> 30 ms, 9 k 248 -> 68, 20 k 267 -> 109, 37 k 264 -> 167, 90 k 291 -> 380 (tools/coop_check.py).
     if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 12u) variant = 1033;
   }
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
@@ -696,8 +696,20 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     uint32_t cap = (uint32_t)g_cus * (16 / NW);  // 4 waves per SIMD at 128 VGPRs
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return RL_OK;
-    HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rtiow_coop_kernel<NW>, dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+    static const int coop_mode = std::getenv("RL_COOP_MODE") ? std::atoi(std::getenv("RL_COOP_MODE")) : -1;  // A/B: 0 L2 boxes, 128 VGPRs; 1 L2 boxes; 2 boxes in registers
+    // the lowest latency (boxes in registers: 3.3 us per ray, two waves per SIMD) while every pixel gets a wave at once; the register
+    // budget of four waves per SIMD (boxes from L2: 4.0 us per ray, +25 % throughput) for larger frames
+    int mode = coop_mode >= 0 ? coop_mode : (n_pixels <= (uint32_t)g_cus * 8u ? 2 : 0);
+    if (mode == 0) {
+      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((rtiow_coop_kernel<NW, false, 1024>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+    } else if (mode == 2) {
+      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, true, NW * 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((rtiow_coop_kernel<NW, true, NW * 64>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, false, NW * 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((rtiow_coop_kernel<NW, false, NW * 64>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+    }
     HIP_TRY(hipGetLastError());
     return RL_OK;
   };

@@ -35,7 +35,9 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 
 // The body: NT threads = NT / 64 waves, each wave claims pixels of C.pixels until the list is exhausted.
 // LDS: [8][NT] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NT / 64][max_cand] u32 candidate lists.
-template <int NT>
+// BOXES_IN_REGS: lane l keeps the leaf boxes of spheres l, l + 64, ... l + 448 in 48 registers (scenes of up to 512 spheres) — the
+// lowest latency per ray; without it the boxes come from L2 every ray and the kernel fits the register budget of four waves per SIMD
+template <int NT, bool BOXES_IN_REGS>
 __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const CoopParams &C, unsigned char *smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long *s_rng = (unsigned long long *)smem;  // [8][NT]
@@ -53,6 +55,16 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
   const float FINF = __int_as_float(0x7F800000);
   const uint32_t n_sph = P.n_spheres;
   uint32_t c_rays = 0, c_flag = 0, c_slow = 0;
+  // up to 512 spheres: lane l tests the leaf boxes of spheres l, l + 64, ... l + 448 for every ray — 48 registers, loaded once
+  const bool boxes_in_regs = BOXES_IN_REGS && n_sph <= 512u;
+  float rb[BOXES_IN_REGS ? 8 : 1][6];
+#pragma unroll
+  for (int k = 0; k < (BOXES_IN_REGS ? 8 : 1); k++) {
+    const uint32_t i = (uint32_t)(k * 64 + lane);
+    Float4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
+    if (boxes_in_regs && i < n_sph) b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
+    rb[k][0] = b0.x, rb[k][1] = b0.y, rb[k][2] = b0.z, rb[k][3] = b0.w, rb[k][4] = b1.x, rb[k][5] = b1.y;
+  }
   const uint32_t n_pixels = C.n_pixels_dev ? *C.n_pixels_dev : C.n_pixels;  // the list's length may have been decided on the device
 
   for (;;) {
@@ -100,14 +112,12 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
           // (1) every lane: the leaf boxes of spheres lane, lane + 64, ... (certain-miss test of the fast traversal, closest = +inf)
           uint32_t ncand = 0;
           __builtin_amdgcn_wave_barrier();  // the previous ray's candidate list is no longer read
-          for (uint32_t base = 0; base < n_sph; base += 64u) {
-            const uint32_t i = base + (uint32_t)lane;
+          auto scan = [&](uint32_t i, float bx0, float bx1, float by0, float by1, float bz0, float bz1) {
             bool cand = false;
             if (i < n_sph) {
-              const Float4 b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
-              float t0x = fmaf(b0.x, ra32.invx, -ra32.oix), t1x = fmaf(b0.y, ra32.invx, -ra32.oix);
-              float t0y = fmaf(b0.z, ra32.invy, -ra32.oiy), t1y = fmaf(b0.w, ra32.invy, -ra32.oiy);
-              float t0z = fmaf(b1.x, ra32.invz, -ra32.oiz), t1z = fmaf(b1.y, ra32.invz, -ra32.oiz);
+              float t0x = fmaf(bx0, ra32.invx, -ra32.oix), t1x = fmaf(bx1, ra32.invx, -ra32.oix);
+              float t0y = fmaf(by0, ra32.invy, -ra32.oiy), t1y = fmaf(by1, ra32.invy, -ra32.oiy);
+              float t0z = fmaf(bz0, ra32.invz, -ra32.oiz), t1z = fmaf(bz1, ra32.invz, -ra32.oiz);
               float tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
               float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
               float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
@@ -119,6 +129,17 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
               if (slot < C.max_cand) s_cand[slot] = i;
             }
             ncand += (uint32_t)__popcll(mask);
+          };
+          if (BOXES_IN_REGS && boxes_in_regs) {  // the lane's own eight boxes never change: they were fetched once, before the first pixel
+#pragma unroll
+            for (int k = 0; k < (BOXES_IN_REGS ? 8 : 1); k++) scan((uint32_t)(k * 64 + lane), rb[k][0], rb[k][1], rb[k][2], rb[k][3], rb[k][4], rb[k][5]);
+          } else {
+            for (uint32_t base = 0; base < n_sph; base += 64u) {
+              const uint32_t i = base + (uint32_t)lane;
+              Float4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
+              if (i < n_sph) b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
+              scan(i, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the candidate list is read by other lanes of this wave
           __builtin_amdgcn_wave_barrier();
@@ -262,10 +283,11 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
 }
 
 // stand-alone form (A/B and tests, RL_RTIOW_KERNEL=coop): every pixel of the list through the cooperative body
-template <int NW>
-__global__ void __launch_bounds__(NW * 64) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
+// REGS_FOR: the workgroup size the register budget is computed for (1024: 128 VGPRs, four waves per SIMD)
+template <int NW, bool BOXES_IN_REGS, int REGS_FOR>
+__global__ void __launch_bounds__(REGS_FOR) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  rtiow_coop_body<NW * 64>(P, C, smem);
+  rtiow_coop_body<NW * 64, BOXES_IN_REGS>(P, C, smem);
 }
 
 }  // namespace rl
