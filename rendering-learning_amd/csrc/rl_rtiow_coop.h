@@ -1,9 +1,9 @@
-// Cooperative latency kernel for the per-pixel sample chain (DESIGN.md §6): ONE WAVE PER PIXEL.
+// Cooperative latency kernel for the per-pixel sample chain (DESIGN.md §3.1c, §6): ONE WAVE PER PIXEL.
 //
 // The samples of a pixel are sequential in the reference (camera.rs:161-174: sample n + 1 starts at the ChaCha word position sample n
-// stopped at), so when a shard has about as many pixels as the GPU has lanes, the frame time is the time of its longest chains — and a
-// chain advances at the latency of one ray through the state machine of rl_rtiow_wave.h (9.6 us for a lone lane, 22.6 us inside a full
-// wave).  This kernel runs the most expensive pixels of such a shard differently: all 64 lanes of a wave carry the SAME pixel (same RNG
+// stopped at), so when a frame has few pixels its time is the time of its longest chains — and a chain advances at the latency of one
+// ray through the state machine of rl_rtiow_wave.h (9.6 us for a lone lane, 22.6 us inside a full wave).  This kernel — what the library
+// renders small frames of sphere scenes with — works differently: all 64 lanes of a wave carry the SAME pixel (same RNG
 // stream, same arithmetic, redundantly — there is no divergence and no scheduler), and the one thing that can be spread over the lanes
 // is: World::hit.  Each lane tests the reject-only binary32 leaf boxes of eight of the scene's spheres (the boxes of rl_fast_bvh.cpp,
 // same certain-miss test as the fast traversal), the candidates are compacted through LDS, one lane per candidate evaluates the
@@ -16,7 +16,7 @@
 namespace rl {
 
 struct CoopParams {
-  const uint32_t *pixels;   // [n_pixels] virtual pixel index pr * W + px (pr = row within the shard), most expensive first
+  const uint32_t *pixels;   // [n_pixels] virtual pixel index pr * W + px (pr = row within the shard)
   uint32_t n_pixels;
   const uint32_t *n_pixels_dev;  // when not null: the length of the list, written by an earlier kernel on the same stream
   const float *leaf_boxes;  // [n_spheres][8]: x.min, x.max, y.min, y.max, z.min, z.max, 0, 0 (padded, rounded outwards)
