@@ -18,7 +18,6 @@ namespace rl {
 struct CoopParams {
   const uint32_t *pixels;   // [n_pixels] virtual pixel index pr * W + px (pr = row within the shard)
   uint32_t n_pixels;
-  const uint32_t *n_pixels_dev;  // when not null: the length of the list, written by an earlier kernel on the same stream
   const float *leaf_boxes;  // [n_spheres][8]: x.min, x.max, y.min, y.max, z.min, z.max, 0, 0 (padded, rounded outwards)
   uint32_t *counter;        // work counter (zeroed before the launch)
   uint32_t max_cand;        // capacity of the per-wave candidate list in LDS
@@ -37,11 +36,9 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 // LDS: [8][NT] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NT / 64][max_cand] u32 candidate lists.
 // BOXES_IN_REGS: lane l keeps the leaf boxes of spheres l, l + 64, ... l + 448 in 48 registers (scenes of up to 512 spheres) — the
 // lowest latency per ray; without it the boxes come from L2 every ray and the kernel fits the register budget of four waves per SIMD
-template <int NT, bool BOXES_IN_REGS>
-__device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const CoopParams &C, unsigned char *smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long *s_rng = (unsigned long long *)smem;  // [8][NT]
-  uint32_t *s_cand = (uint32_t *)(smem + (size_t)8 * NT * sizeof(unsigned long long)) + (size_t)wave * C.max_cand;
+template <int NT, bool BOXES_IN_REGS, class Source, class Cand>
+__device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const float *leaf_boxes, uint32_t max_cand, unsigned long long *s_rng, Cand cand_at, Source src) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const DevOp *ops = P.ops;
   const DevSphere *spheres = P.spheres;
   RngCtx<NT> rc{P.key, s_rng, tid};
@@ -62,27 +59,18 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
   for (int k = 0; k < (BOXES_IN_REGS ? 8 : 1); k++) {
     const uint32_t i = (uint32_t)(k * 64 + lane);
     Float4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
-    if (boxes_in_regs && i < n_sph) b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
+    if (boxes_in_regs && i < n_sph) b0 = *(const Float4 *)(leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(leaf_boxes + (size_t)i * 8 + 4);
     rb[k][0] = b0.x, rb[k][1] = b0.y, rb[k][2] = b0.z, rb[k][3] = b0.w, rb[k][4] = b1.x, rb[k][5] = b1.y;
   }
-  const uint32_t n_pixels = C.n_pixels_dev ? *C.n_pixels_dev : C.n_pixels;  // the list's length may have been decided on the device
 
   for (;;) {
-    uint32_t idx = 0;
-    if (lane == 0) idx = atomicAdd(C.counter, 1u);
-    idx = __shfl(idx, 0, 64);
-    if (idx >= n_pixels) break;
-    const uint32_t pix = C.pixels[idx];
+    uint32_t pix = 0, n_begin = 0, pos0 = 0;
+    D3 sum = d3(0.0, 0.0, 0.0);
+    if (!src.next(P, lane, pix, sum, pos0, n_begin)) break;
     const uint32_t x = pix % W, r = pix / W;
     const uint32_t y = P.row_first + r * P.row_step;
-    Rng rng{0ull, 0u, 0xFFFFFFFFu};
-    D3 sum = d3(0.0, 0.0, 0.0);
-    if (P.resume) {  // continue where the previous launch stopped: same sums, same ChaCha word position
-      const double *inp = P.out + (size_t)pix * 3;
-      sum = d3(inp[0], inp[1], inp[2]);
-      rng.pos = P.pos_state[pix];
-    }
-    for (uint32_t n = P.sample_begin; n < P.sample_end; n++) {
+    Rng rng{0ull, pos0, 0xFFFFFFFFu};
+    for (uint32_t n = n_begin; n < P.sample_end; n++) {
       uint64_t sample_index = (uint64_t)n + P.first_sample;
       rng.stream = sample_index * WH + (uint64_t)x * (uint64_t)W + (uint64_t)y;  // camera.rs:167-169 (x*W, sic)
       rng.buf_ctr = 0xFFFFFFFFu;
@@ -126,7 +114,7 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
             const unsigned long long mask = __ballot(cand);
             if (cand) {
               const uint32_t slot = ncand + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-              if (slot < C.max_cand) s_cand[slot] = i;
+              if (slot < max_cand) cand_at(slot) = i;
             }
             ncand += (uint32_t)__popcll(mask);
           };
@@ -137,13 +125,13 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
             for (uint32_t base = 0; base < n_sph; base += 64u) {
               const uint32_t i = base + (uint32_t)lane;
               Float4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
-              if (i < n_sph) b0 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(C.leaf_boxes + (size_t)i * 8 + 4);
+              if (i < n_sph) b0 = *(const Float4 *)(leaf_boxes + (size_t)i * 8), b1 = *(const Float4 *)(leaf_boxes + (size_t)i * 8 + 4);
               scan(i, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the candidate list is read by other lanes of this wave
           __builtin_amdgcn_wave_barrier();
-          if (ncand > C.max_cand) amb = true;  // more candidates than the list holds: the reference's fold
+          if (ncand > max_cand) amb = true;  // more candidates than the list holds: the reference's fold
           else {
             // (2) one lane per candidate: Sphere::hit (sphere.rs:32-75) with ray_t = [1e-10, +inf): same arithmetic, same roots as
             // fast_sphere_hit; (3) wave reduction: closest root, runner-up and the widest tie band seen
@@ -155,7 +143,7 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
               uint32_t payload_k = NONE;
               bool sens_k = false;
               if (k < ncand) {
-                const uint32_t si = s_cand[k];
+                const uint32_t si = cand_at(k);
                 const uint32_t payload = si | (((P.movbits[si >> 5] >> (si & 31u)) & 1u) ? SPH_MOVING : 0u);
                 const DevSphere &s = spheres[si];
                 D3 c0v = ld3(s.c0);
@@ -268,11 +256,7 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
       }
       sum = sum + color;
     }
-    if (lane == 0) {
-      double *outp = P.out + (size_t)pix * 3;
-      outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
-      if (P.pos_state) P.pos_state[pix] = rng.pos;
-    }
+    src.finish(P, lane, pix, sum, rng.pos);
   }
   // every lane of a wave counted the same rays: lane 0 reports
   if (lane == 0) {
@@ -282,12 +266,48 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const Coop
   }
 }
 
-// stand-alone form (A/B and tests, RL_RTIOW_KERNEL=coop): every pixel of the list through the cooperative body
+// Work source of the stand-alone kernel: the pixels of a list, each from the state the previous launch left (P.resume) or from scratch
+struct CoopListSource {
+  const uint32_t *pixels;
+  uint32_t n_pixels;
+  uint32_t *counter;
+  __device__ __forceinline__ bool next(const RtiowParams &P, int lane, uint32_t &pix, D3 &sum, uint32_t &pos, uint32_t &n_begin) const {
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(counter, 1u);
+    idx = __shfl(idx, 0, 64);
+    if (idx >= n_pixels) return false;
+    pix = pixels[idx];
+    n_begin = P.sample_begin, pos = 0u, sum = d3(0.0, 0.0, 0.0);
+    if (P.resume) {  // continue where the previous launch stopped: same sums, same ChaCha word position
+      const double *inp = P.out + (size_t)pix * 3;
+      sum = d3(inp[0], inp[1], inp[2]);
+      pos = P.pos_state[pix];
+    }
+    return true;
+  }
+  __device__ __forceinline__ void finish(const RtiowParams &P, int lane, uint32_t pix, D3 sum, uint32_t pos) const {
+    if (lane == 0) {
+      double *outp = P.out + (size_t)pix * 3;
+      outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+      if (P.pos_state) P.pos_state[pix] = pos;
+    }
+  }
+};
+struct CoopLinearCand {  // candidate list of a wave: max_cand consecutive words
+  uint32_t *base;
+  __device__ __forceinline__ uint32_t &operator()(uint32_t k) const { return base[k]; }
+};
+
+// stand-alone form (small frames, RL_RTIOW_KERNEL=coop): every pixel of the list through the cooperative body.
+// NW waves per workgroup; LDS: [8][NW * 64] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NW][max_cand] u32.
 // REGS_FOR: the workgroup size the register budget is computed for (1024: 128 VGPRs, four waves per SIMD)
 template <int NW, bool BOXES_IN_REGS, int REGS_FOR>
 __global__ void __launch_bounds__(REGS_FOR) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  rtiow_coop_body<NW * 64, BOXES_IN_REGS>(P, C, smem);
+  constexpr int NT = NW * 64;
+  unsigned long long *s_rng = (unsigned long long *)smem;
+  uint32_t *s_cand = (uint32_t *)(smem + (size_t)8 * NT * sizeof(unsigned long long)) + (size_t)(threadIdx.x >> 6) * C.max_cand;
+  rtiow_coop_body<NT, BOXES_IN_REGS>(P, C.leaf_boxes, C.max_cand, s_rng, CoopLinearCand{s_cand}, CoopListSource{C.pixels, C.n_pixels, C.counter});
 }
 
 }  // namespace rl
