@@ -255,6 +255,13 @@ def set_coop(on):
     render_lib().rl_debug_set_coop(int(bool(on)))
 
 
+def set_steal(max_fill):
+    """Tests / tools: work stealing on small shards (at most max_fill x as many pixels as the GPU has lanes; 0 switches it off)."""
+    L = render_lib()
+    L.rl_debug_set_steal.argtypes = [C.c_double]
+    L.rl_debug_set_steal(float(max_fill))
+
+
 def has_experimental():
     return bool(render_lib().rl_debug_has_experimental())
 

@@ -42,6 +42,8 @@ size_t g_lds_max = 65536;
 int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
 bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
 bool g_coop_small = true;  // small frames through the cooperative kernel (RL_COOP=0 disables; A/B only)
+// work stealing on small shards: used when the shard has at most g_steal_max_fill x as many pixels as the GPU has lanes (RL_STEAL=<fill>, 0 = off)
+double g_steal_max_fill = 3.0;
 unsigned long long g_last_slow_traces = 0;
 bool g_fast_debug_stats = false;  // tools only: counting renders run the fast kernel too (counters are then NOT the reference's)
 bool g_fast_traversal = true;  // counter-free renders of LDS-sized sphere scenes use the fast traversal (RL_FAST=0 disables; A/B only)
@@ -172,6 +174,7 @@ int rl_init(int device) {
   }
   if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
   if (const char *v = std::getenv("RL_COOP")) g_coop_small = std::string(v) != "0";
+  if (const char *v = std::getenv("RL_STEAL")) g_steal_max_fill = std::atof(v);
   if (const char *v = std::getenv("RL_FAST")) g_fast_traversal = std::string(v) != "0";
   g_ready = true;
   return RL_OK;
@@ -202,7 +205,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_steal_state), hipFree(s->d_steal_n), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -684,6 +687,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     // 2.2 k pixels 184 -> 30 ms, 9 k 248 -> 68, 20 k 267 -> 109, 37 k 264 -> 167, 90 k 291 -> 380 (tools/coop_check.py).
     if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 12u) variant = 1033;
   }
+  bool steal = false;  // set for the resume launch of a small shard (variant 1029)
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
     constexpr int NW = 4;
     CoopParams C{};
@@ -798,7 +802,8 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;
       // <.., 4, true> only under rl_debug_fast_stats (tools/sched.py): scheduler occupancy of the fast kernel; its box / sphere counts are its own
-      rc = want_stats ? launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
+      if (steal) rc = launch(rtiow_wave_kernel<NT, 4, false, true>, NT, rb, false);
+      else rc = want_stats ? launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
     } else if (variant == 1027) {  // 4 waves per SIMD: rings + compact guarded ops in LDS, spheres read from L2
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + compact_bytes;
@@ -855,6 +860,21 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
+    if (variant == 1029 && !want_stats && g_steal_max_fill > 0.0 && (double)npix <= g_steal_max_fill * (double)g_cus * 1024.0) {
+      // small shard: waves that run out of pixels take over pixels other lanes are still rendering (rl_rtiow_coop.h rtiow_steal_loop)
+      if (ms->steal_pix < npix) {
+        hipFree(ms->d_steal_state), hipFree(ms->d_steal_n);
+        ms->d_steal_state = ms->d_steal_n = nullptr, ms->steal_pix = 0;
+        HIP_TRY(hipMalloc((void **)&ms->d_steal_state, npix * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&ms->d_steal_n, npix * sizeof(uint32_t)));
+        ms->steal_pix = npix;
+      }
+      HIP_TRY(hipMemsetAsync(ms->d_steal_state, 0, npix * sizeof(uint32_t), stream));
+      HIP_TRY(hipMemsetAsync(scene->d_scratch + 256, 0, 4, stream));
+      P.steal_state = ms->d_steal_state, P.steal_n = ms->d_steal_n, P.steal_counter = (uint32_t *)(scene->d_scratch + 256);
+      P.coop_leaf_boxes = scene->d_fast_leaf_boxes;
+      steal = true;
+    }
     if (variant == 1029) {
       // latency modes (A/B only, default off): RL_THIN=<permille of the tiles> renders the most expensive tiles
       // 64 >> RL_THIN_SHIFT pixels per wave, RL_PRIO=<permille> raises the issue priority of the waves that hold them.  Measured on the
@@ -1058,6 +1078,7 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
 void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
 void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
 void rl_debug_set_coop(int on) { g_coop_small = on != 0; }
+void rl_debug_set_steal(double max_fill) { g_steal_max_fill = max_fill; }
 void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
 void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
 #ifdef RL_FASTG_VERIFY

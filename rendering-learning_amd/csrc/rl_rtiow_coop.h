@@ -310,4 +310,68 @@ __global__ void __launch_bounds__(REGS_FOR) rtiow_coop_kernel(RtiowParams P, Coo
   rtiow_coop_body<NT, BOXES_IN_REGS>(P, C.leaf_boxes, C.max_cand, s_rng, CoopLinearCand{s_cand}, CoopListSource{C.pixels, C.n_pixels, C.counter});
 }
 
+// ---- work stealing (the STEAL instantiation of rtiow_wave_kernel, small shards): see RtiowParams::steal_state
+// Candidates are the pixels of the tiles in the cost-sorted order of the resume launch, most expensive first.  A wave asks for one
+// (0 -> 1), waits until the lane that renders it reaches its next sample boundary and releases it (2: P.out, pos_state and steal_n hold
+// the sums, the ChaCha word position and the next sample), and continues it with all 64 lanes.  Every wait is bounded: a request that
+// is not answered in time is withdrawn (1 -> 0) and the pixel stays where it is.
+struct CoopStealSource {
+  __device__ __forceinline__ bool next(const RtiowParams &P, int lane, uint32_t &pix, D3 &sum, uint32_t &pos, uint32_t &n_begin) const {
+    const uint32_t W = P.cam.image_width;
+    for (;;) {
+      uint32_t k = 0;
+      if (lane == 0) k = atomicAdd(P.steal_counter, 1u);
+      k = __shfl(k, 0, 64);
+      if (k >= P.n_slots) return false;  // every candidate has been offered
+      const uint32_t tile = P.tile_order[k >> 6], in = k & 63u;
+      const uint32_t x = (tile % P.tiles_x) * 8u + (in & 7u), r = (tile / P.tiles_x) * 8u + (in >> 3);
+      if (x >= W || r >= P.nrows) continue;
+      pix = r * W + x;
+      uint32_t s = 0;
+      if (lane == 0) s = atomicCAS(&P.steal_state[pix], 0u, 1u);
+      s = __shfl(s, 0, 64);
+      if (s != 0u) continue;  // finished already (3)
+      s = 1u;
+      for (int spins = 0; spins < 16384; spins++) {  // a sample of the busiest pixels takes up to ~2 ms; each round sleeps ~1 us
+        if (lane == 0) s = __atomic_load_n(&P.steal_state[pix], __ATOMIC_RELAXED);
+        s = __shfl(s, 0, 64);
+        if (s != 1u) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+      if (s == 1u) {  // not answered: withdraw the request, unless the answer arrives right now
+        if (lane == 0) s = atomicCAS(&P.steal_state[pix], 1u, 0u);
+        s = __shfl(s, 0, 64);
+        if (s == 1u) continue;
+      }
+      if (s != 2u) continue;  // the pixel finished meanwhile
+      __threadfence();        // acquire: what the releasing lane wrote
+      const volatile double *inp = P.out + (size_t)pix * 3;
+      sum = d3(inp[0], inp[1], inp[2]);
+      pos = ((const volatile uint32_t *)P.pos_state)[pix];
+      n_begin = ((const volatile uint32_t *)P.steal_n)[pix];
+      return true;
+    }
+  }
+  __device__ __forceinline__ void finish(const RtiowParams &P, int lane, uint32_t pix, D3 sum, uint32_t pos) const {
+    if (lane == 0) {
+      double *outp = P.out + (size_t)pix * 3;
+      outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+      P.pos_state[pix] = pos;
+      atomicExch(&P.steal_state[pix], 3u);
+    }
+  }
+};
+template <int NT>
+struct CoopRingCand {  // candidate list of a wave inside its own (now idle) ChaCha ring columns: rows 8 and 9 of [16][NT] u64, low words
+  unsigned long long *s_rng;
+  int wave;
+  __device__ __forceinline__ uint32_t &operator()(uint32_t k) const {
+    return *(uint32_t *)(s_rng + ((size_t)(8u + (k >> 6)) * NT + (size_t)wave * 64u + (k & 63u)));
+  }
+};
+template <int NT>
+__device__ __forceinline__ void rtiow_steal_loop(const RtiowParams &P, unsigned long long *s_rng) {
+  rtiow_coop_body<NT, false>(P, P.coop_leaf_boxes, 128u, s_rng, CoopRingCand<NT>{s_rng, (int)(threadIdx.x >> 6)}, CoopStealSource{});
+}
+
 }  // namespace rl

@@ -56,7 +56,12 @@ struct RtiowParams {
   uint32_t tune[4];           // wave kernel: [0] max TRAV steps per scheduling round, [1] leave-TRAV population floor in 1/16ths
   uint32_t thin_tiles;        // fast wave kernel, resume launch: the first thin_tiles tiles of tile_order are handed out 64 >> thin_shift pixels per wave
   uint32_t thin_shift;        // 2 (16 pixels per wave) .. 6 (one pixel per wave)
-  uint32_t prio_tiles;        // fast wave kernel, resume launch (A/B): a wave holding a pixel of the first prio_tiles tiles runs at s_setprio 3
+  uint32_t prio_tiles;
+  // work stealing on small shards (rl_rtiow_wave.h STEAL instantiation): a wave whose lanes have all run out of pixels takes over pixels
+  // other lanes are still rendering, at a sample boundary, and continues them with the cooperative one-wave-per-pixel body.
+  // steal_state[pix]: 0 queued / running, 1 take-over requested, 2 released (P.out, pos_state and steal_n hold the state), 3 finished
+  uint32_t *steal_state, *steal_n, *steal_counter;
+  const float *coop_leaf_boxes;        // fast wave kernel, resume launch (A/B): a wave holding a pixel of the first prio_tiles tiles runs at s_setprio 3
   uint32_t *pix_rays;         // debug (tools/): per-pixel ray counts, accumulated at pixel end by the counting wave kernel, or null
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
 };

@@ -321,7 +321,13 @@ __device__ __forceinline__ uint32_t fast_slow_trace(const DevOp *ops, const DevS
   return flags;
 }
 
-template <int NT, int LDS_SCENE, bool STATS>
+// rl_rtiow_coop.h (included after this header): what a wave of the STEAL instantiation runs once all its lanes have run out of pixels
+template <int NT>
+__device__ __forceinline__ void rtiow_steal_loop(const RtiowParams &P, unsigned long long *s_rng);
+
+// STEAL (LDS_SCENE = 4, counter-free, the cost-sorted resume launch of a small shard): lanes hand a pixel over, at a sample boundary, to
+// a wave that asks for it (P.steal_state), and a wave without work left asks — see rtiow_steal_loop
+template <int NT, int LDS_SCENE, bool STATS, bool STEAL = false>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -709,11 +715,26 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     } else if (pick == ST_GEN) {
       if (state == ST_GEN) {
         bool active = true;
+        if (STEAL && P.steal_state && have_pixel && n < spp) {  // a sample boundary: has a wave without work asked for this pixel?
+          const size_t pix = (size_t)pr * W + px;
+          if (__atomic_load_n(&P.steal_state[pix], __ATOMIC_RELAXED) == 1u) {
+            double *outp = P.out + pix * 3;
+            outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+            P.pos_state[pix] = rng.pos;
+            P.steal_n[pix] = n;
+            __threadfence();  // the state above is visible before the release
+            if (atomicCAS(&P.steal_state[pix], 1u, 2u) == 1u) {
+              have_pixel = false;
+              n = spp;  // -> claim (the queue is empty by now: the lane is done)
+            }  // else: the request was withdrawn in the meantime — the pixel stays here
+          }
+        }
         if (n >= spp) {  // pixel finished (or none yet): write it out, claim the next slot
           if (have_pixel) {
             size_t pix = (size_t)pr * W + px;
             double *outp = P.out + pix * 3;
             outp[0] = sum.x, outp[1] = sum.y, outp[2] = sum.z;
+            if (STEAL && P.steal_state) atomicExch(&P.steal_state[pix], 3u);  // finished: a request that arrives now finds nothing to take
             if (P.pos_state) P.pos_state[pix] = rng.pos;               // resumable: the next launch continues this pixel
             if (P.tile_cost) atomicAdd(&P.tile_cost[ptile], pix_rays);  // cost estimate for the LPT order of the next launch
             if (STATS && !P.tile_cost) c_words += rng.pos;
@@ -828,6 +849,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     }
   }
 
+  if (STEAL && LDS_SCENE == 4 && P.steal_state) {
+    // every lane of this wave is out of work: take over pixels that other lanes are still rendering (most expensive tiles first) and
+    // run them one at a time with all 64 lanes (its own counters go to P.stats from there)
+    rtiow_steal_loop<NT>(P, rng.s_rng);
+  }
   unsigned long long v;
   v = wave_sum((unsigned long long)c_rays);
   if ((tid & 63) == 0 && v) atomicAdd(&P.stats[0], v);

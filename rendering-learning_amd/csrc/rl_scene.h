@@ -58,6 +58,8 @@ struct rl_scene {
   float *d_fast_leaf_boxes = nullptr;
   uint32_t *d_coop_pixels = nullptr;  // cooperative kernel: pixel list (scratch, grown on demand)
   size_t coop_pixels_cap = 0;
+  uint32_t *d_steal_state = nullptr, *d_steal_n = nullptr;  // work stealing on small shards (RtiowParams::steal_state)
+  size_t steal_pix = 0;
   rl::FastNodeQ *d_fg_nodes = nullptr;
   rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_fg_spheres = nullptr;
