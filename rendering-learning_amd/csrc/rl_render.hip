@@ -682,10 +682,11 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
     bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
     variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
-    // Small frames (at most ~12 pixels per wave the GPU can hold) are pure latency: every pixel's sample chain runs alone, and the
+    // Small frames (at most 10 pixels per wave the GPU can hold) are pure latency: every pixel's sample chain runs alone, and the
     // cooperative one-wave-per-pixel kernel advances a chain in 3.9 us per ray instead of ~22 (rl_rtiow_coop.h).  Measured at 1024 spp:
-    // 2.2 k pixels 184 -> 30 ms, 9 k 248 -> 68, 20 k 267 -> 109, 37 k 264 -> 167, 90 k 291 -> 380 (tools/coop_check.py).
-    if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 12u) variant = 1033;
+    // 2.2 k pixels 184 -> 30 ms, 9 k 248 -> 68, 20 k 267 -> 109, 37 k 264 -> 167, 90 k 291 -> 380 (tools/coop_check.py); from ~40 k
+    // pixels on the wave-scheduled kernel with work stealing is as fast or faster (37 k: 173 ms, 90 k: 170 ms; tools/steal_ab.py).
+    if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 10u) variant = 1033;
   }
   bool steal = false;  // set for the resume launch of a small shard (variant 1029)
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {

@@ -25,7 +25,7 @@ def test_work_stealing_renders_the_same_bits(rl, oracle, width, spp, shard):
     p.image_width, p.samples_per_pixel, p.max_depth = width, spp, 50
     cam = rl.Camera(p)
     npix = rl.api.rows_for(cam.c.image_height, 0, shard) * cam.c.image_width
-    assert 49152 < npix <= 3 * 256 * 1024  # above the cooperative kernel's small-frame limit, within the stealing rule
+    assert 40960 < npix <= 3 * 256 * 1024  # above the cooperative kernel's small-frame limit, within the stealing rule
     frames = []
     try:
         for fill in (3.0, 0.0, 3.0, 3.0):  # stealing on / off / on / on: the take-overs differ from run to run, the bits must not
