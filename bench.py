@@ -247,6 +247,12 @@ def main():
                                  "HBM traffic is the framebuffer"})
         else:
             roof.update({"achieved": None, "frac": None, "note": "no profiles/valu.json for this workload: VALU figures not available"})
+        # a rank whose shard has at most three pixels per lane renders its resume launch with the work-stealing instantiation:
+        # taken-over pixels run through the cooperative body, whose instruction mix valu.json (profiled at N = 1) does not describe
+        rank_pixels = rl.api.rows_for(H, row_first, row_step) * W
+        if rank_pixels <= 3 * N_CU * 1024 and os.environ.get("RL_STEAL", "3") not in ("0", "0.0"):
+            roof["kernel"] = "rtiow_wave_kernel<1024,4,false,true> (work stealing)"
+            roof["note"] = (roof.get("note") or "") + "; this rank's shard is small enough for work stealing: the VALU figures are those of the N = 1 kernel and only indicative here"
         out = {
             "metric": "Mrays/sec (primary+secondary), 1080p 1024spp depth50; 1/2/4/8 GPU",
             "value": value, "unit": "Mrays/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
