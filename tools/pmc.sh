@@ -16,11 +16,11 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --no-cpu-baseline --no-check --steps 1 --warmup 1 --spp $SPP "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; }
   python3 - <<PY | tee -a $OUT/summary.txt
-import csv,glob,collections
+import csv,glob,collections,re
 acc=collections.defaultdict(float)
 for f in glob.glob("$OUT/p$i/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if ("rtiow" in r["Kernel_Name"] or "rtc_" in r["Kernel_Name"]) and "false>" in r["Kernel_Name"]:
+        if re.search(r"rtiow_wave_kernel<\d+, \d+, false|rtiow_fast_general_kernel|rtiow_coop_kernel|rtc_kernel|rtc_full_kernel", r["Kernel_Name"]):  # the TIMED (counter-free) instantiations
             acc[r["Counter_Name"]]+=float(r["Counter_Value"])
 for k,v in acc.items(): print(k, v)
 PY

@@ -15,12 +15,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --no-cpu-baseline --no-check "$@" --steps 1 --warmup 1 > $OUT/pmc_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 $OUT/pmc_$c.log; exit 1; }
 done
 python3 - <<PY | tee $OUT/hbm.txt
-import csv, glob, collections
+import csv, glob, collections, re
 acc = collections.defaultdict(float); n = collections.defaultdict(int)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob("$OUT/pmc_%s/*/*counter_collection.csv" % c):
         for r in csv.DictReader(open(f)):
-            if "rtiow_wave_kernel" in r["Kernel_Name"] and "false>" in r["Kernel_Name"]:
+            if re.search(r"rtiow_wave_kernel<\d+, \d+, false", r["Kernel_Name"]):  # the TIMED (counter-free) instantiation
                 acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 # MI355X_MICROARCH.md §HBM: both counters are in KiB on gfx950 and FETCH_SIZE reports half of the bytes fetched
 fetch, write = acc["FETCH_SIZE"], acc["WRITE_SIZE"]
