@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run frame check (profiling passes)")
     ap.add_argument("--check-rows", type=int, default=8)
+    ap.add_argument("--configs", default="cfg3,cfg4,cfg5", help="non-headline BASELINE configs appended to the line at N = 1 ('' = none)")
+    ap.add_argument("--cfg4-spp", type=int, default=512)
+    ap.add_argument("--cfg5-spp", type=int, default=256)
     ap.add_argument("--inprocess", action="store_true", help="N GPUs from ONE process through rl_init_multi / rl_rtiow_render_multi_device")
     ap.add_argument("--emulate-shard", type=int, default=0,
                     help="single-GPU rehearsal of an N-way shard: render only rows 0 mod N (not the headline metric)")
@@ -84,6 +87,214 @@ def valu_profile(W, H, spp, depth):
     except Exception:
         return None
     return vj if vj.get("workload_scene") == "bouncing_spheres(1)" and vj.get("depth") == depth and vj.get("width") == W else None
+
+
+def cfg_profile(tag):
+    """rocprofv3 figures of a non-headline config's timed kernel (profiles/roofline_<tag>.json, written by tools/pmc_mem.sh + tools/pmc_cfg.sh)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"roofline_{tag}.json")))
+    except Exception:
+        return None
+
+
+def cfg_roofline(tag, rays, kernel_s, alg_bytes):
+    """The roofline object of one `configs` entry: this run's rays and kernel time x the per-ray counter figures of profiles/."""
+    roof = {"algorithmic_bytes_per_ray": alg_bytes / max(1.0, rays), "algorithmic_gbs": alg_bytes / kernel_s / 1e9,
+            "hbm_peak_gbs": 8000.0, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS}
+    pj = cfg_profile(tag)
+    if not pj:
+        roof["note"] = f"no profiles/roofline_{tag}.json: counter figures not available"
+        return roof
+    rps = rays / kernel_s
+    roof["kernel"] = pj.get("kernel")
+    roof["per_ray_figures_from"] = pj.get("source")
+    if pj.get("valu_lane_ops_per_ray_f32_weighted") is not None:
+        ach = pj["valu_lane_ops_per_ray_f32_weighted"] * rps / 1e12
+        roof.update({"valu_achieved_tlaneops": ach, "valu_frac": ach / VALU_PEAK_TLANEOPS,
+                     "valu_issue_frac": pj["valu_issue_slots_per_ray"] * rps / (N_CU * N_SIMD * CLOCK_GHZ * 1e9 / 2.0),
+                     "lanes_active_frac": pj.get("lanes_active_frac"), "wave_cycle_shares": pj.get("wave_cycle_shares")})
+    if pj.get("hbm_bytes_per_ray") is not None:  # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / rays: bytes that left L2 for the Infinity Cache / HBM
+        roof.update({"hbm_bytes_per_ray": pj["hbm_bytes_per_ray"], "hbm_gbs": pj["hbm_bytes_per_ray"] * rps / 1e9,
+                     "hbm_frac": pj["hbm_bytes_per_ray"] * rps / 8e12})
+    for k in ("l2_hit_rate", "l2_bytes_per_ray", "dram_read_bytes_per_ray", "l1_hit_rate", "tcp_tcc_read_latency_cycles", "tcc_ea_read_latency_cycles",
+              "utcl1_miss_rate", "bound"):
+        if pj.get(k) is not None:
+            roof[k] = pj[k]
+    if pj.get("l2_bytes_per_ray") is not None:
+        roof["l2_gbs"] = pj["l2_bytes_per_ray"] * rps / 1e9
+    if pj.get("dram_read_bytes_per_ray") is not None:
+        roof["dram_read_gbs"] = pj["dram_read_bytes_per_ray"] * rps / 1e9
+    return roof
+
+
+def cpu_sample_rtiow(rl, oracle, np, world, p, threads, target_s, stride):
+    """The CPU oracle over a bounded pixel sample of an RTIOW workload (every `stride`-th row and column, spp calibrated by a 1-spp probe)."""
+    cam1 = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": 1}))
+    W, H = cam1.c.image_width, cam1.c.image_height
+    gx, gy = np.meshgrid(np.arange(0, W, stride, dtype=np.uint32), np.arange(0, H, stride, dtype=np.uint32))
+    gx, gy = gx.ravel(), gy.ravel()
+    c0 = time.perf_counter()
+    oracle.rtiow_render_pixels(world.desc, cam1.c, gx, gy, threads=threads)
+    pdt = max(time.perf_counter() - c0, 1e-3)
+    cspp = int(max(1, min(p.samples_per_pixel, target_s / pdt)))
+    ccam = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": cspp}))
+    cst = {}
+    c0 = time.perf_counter()
+    oracle.rtiow_render_pixels(world.desc, ccam.c, gx, gy, threads=threads, stats=cst)
+    cdt = time.perf_counter() - c0
+    return {"value": cst["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene/camera {W}x{H} depth {p.max_depth}: every {stride}th row and column ({len(gx)} pixels), {cspp} spp, {cst['rays']} rays in {cdt:.1f} s "
+                      f"on {threads} threads (one task per pixel); CPU restatement of the reference algorithm (oracle/), not the Rust reference"}
+
+
+def bench_rtiow_config(rl, oracle, np, torch, dev, name, tag, baseline_config, world, p, threads, check_rows, cpu_target_s, cpu_stride, log):
+    """One non-headline RTIOW config at its stated size: counting render (the reference's counters), ONE timed counter-free frame (HIP events on
+    the launch stream), the timed frame against the counting frame and against oracle rows, roofline figures, CPU sample."""
+    cam = rl.Camera(p)
+    W, H = cam.c.image_width, cam.c.image_height
+    stream = torch.cuda.current_stream(dev)
+    warm = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": 1}))
+    buf = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    warm.render_device(world, buf.data_ptr(), stream=stream.cuda_stream)  # code-object load, clocks
+    rl.api.render_status(world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    cam.render_device(world, buf.data_ptr(), stream=stream.cuda_stream)
+    e1.record(stream)
+    status = rl.api.render_status(world)
+    torch.cuda.synchronize(dev)
+    timed_ms = e0.elapsed_time(e1)
+    log(f"{tag}: timed frame {timed_ms:.0f} ms, {status['rays']} rays")
+    st = {}
+    cbuf = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    cam.render_device(world, cbuf.data_ptr(), stream=stream.cuda_stream, stats=st)  # counting (reference-order) kernel, untimed
+    torch.cuda.synchronize(dev)
+    log(f"{tag}: counting frame {st['kernel_ms']:.0f} ms")
+    alg = 64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 128.0 * st["planar_tests"] + 216.0 * st["instance_enters"] + 208.0 * st["rays"]
+    chk = {"timed_frame_equals_counting_frame": bool(torch.equal(buf, cbuf)), "timed_rays_equal_counting_rays": int(status["rays"]) == int(st["rays"]),
+           "flagged": int(st["flagged"]), "slow_traces": int(status.get("slow_traces", 0))}
+    del cbuf
+    rows = max(1, min(check_rows, H))
+    cstep = max(1, H // rows)
+    cfirst = cstep // 2
+    ys = np.arange(cfirst, H, cstep, dtype=np.uint32)
+    rows_buf = torch.zeros((len(ys), W, 3), dtype=torch.float64, device=dev)
+    rs = {}
+    cam.render_device(world, rows_buf.data_ptr(), stream=stream.cuda_stream, row_first=cfirst, row_step=cstep, stats=rs)
+    torch.cuda.synchronize(dev)
+    gx, gy = np.meshgrid(np.arange(W, dtype=np.uint32), ys)
+    cs = {}
+    c0 = time.perf_counter()
+    cpu = oracle.rtiow_render_pixels(world.desc, cam.c, gx.ravel(), gy.ravel(), stats=cs).reshape(len(ys), W, 3)
+    cdt = time.perf_counter() - c0
+    timed_rows = buf[torch.as_tensor(ys.astype(np.int64), device=dev)]
+    chk.update({"rows_checked": int(len(ys)), "pixels_checked": int(len(ys) * W), "spp": p.samples_per_pixel,
+                "timed_rows_equal_row_shard_render": bool(torch.equal(timed_rows, rows_buf)),
+                "counters_equal": all(int(rs[k]) == int(cs[k]) for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged")),
+                "max_abs_err": float(np.abs(timed_rows.cpu().numpy() - cpu).max() / max(1, p.samples_per_pixel)), "tolerance": 1e-4, "oracle_seconds": cdt})
+    log(f"{tag}: oracle rows {cdt:.1f} s")
+    rays = float(status["rays"])
+    out = {"baseline_config": baseline_config, "workload": name, "rays_per_step": rays, "steps": 1, "ms_per_step": timed_ms, "Mrays_s": rays / timed_ms / 1e3,
+           "counting_kernel_ms": st["kernel_ms"], "counting_Mrays_s": st["rays"] / st["kernel_ms"] / 1e3,
+           "per_ray_reference_counts": {k: st[k] / max(1, st["rays"]) for k in ("node_tests", "sphere_tests", "planar_tests", "instance_enters")},
+           "check": chk, "roofline": cfg_roofline(tag, rays, timed_ms * 1e-3, alg)}
+    out["cpu_baseline"] = cpu_sample_rtiow(rl, oracle, np, world, p, threads, cpu_target_s, cpu_stride)
+    log(f"{tag}: cpu sample done")
+    return out
+
+
+def bench_rtc_config(rl, oracle, np, torch, dev, world, aa, frames, threads, tag, log):
+    """BASELINE configs[2] (RTC teapot, 1920x1080): `frames` back-to-back frames through rl_rtc_render_device, HIP events on the launch stream."""
+    cam = world.camera
+    W, H = cam.hsize, cam.vsize
+    stream = torch.cuda.current_stream(dev)
+    buf = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    st = {}
+    cbuf = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    world.render_device(cbuf.data_ptr(), aa, stream=stream.cuda_stream, stats=st)  # counting instantiation (also the warm-up)
+    world.render_device(buf.data_ptr(), aa, stream=stream.cuda_stream)
+    rl.api.render_status(world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(frames):
+        world.render_device(buf.data_ptr(), aa, stream=stream.cuda_stream)
+    e1.record(stream)
+    status = rl.api.render_status(world)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / frames
+    rays = float(st["rays"])
+    cstep = 40
+    cs = {}
+    c0 = time.perf_counter()
+    cpu = oracle.rtc_render(world.desc, cam, aa=aa, row_first=0, row_step=cstep, threads=threads, stats=cs)
+    cdt = time.perf_counter() - c0
+    rs = {}
+    world.render(aa, row_first=0, row_step=cstep, stats=rs)
+    chk = {"timed_frame_equals_counting_frame": bool(torch.equal(buf, cbuf)), "timed_rays_equal_counting_rays": int(status["rays"]) == int(st["rays"]),
+           "rows_checked": int(cpu.shape[0]), "counters_equal": all(int(rs[k]) == int(cs[k]) for k in ("rays", "node_tests", "planar_tests")),
+           "max_abs_err": float(np.abs(buf.cpu().numpy()[0::cstep] - cpu).max()), "tolerance": 1e-4}
+    alg = 48.0 * st["node_tests"] + 72.0 * st["planar_tests"]
+    out = {"baseline_config": "configs[2]", "workload": f"RTC teapot-low.obj (240 triangles, 1 light), {W}x{H}, Phong, AA {aa} ({aa * aa} rays per pixel + shadow rays)",
+           "rays_per_step": rays, "steps": frames, "ms_per_step": ms, "Mrays_s": rays / ms / 1e3,
+           "per_ray_reference_counts": {"bounds_tests": st["node_tests"] / rays, "triangle_tests": st["planar_tests"] / rays},
+           "check": chk, "roofline": cfg_roofline(tag, rays, ms * 1e-3, alg),
+           "cpu_baseline": {"value": cs["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                            "sample": f"same scene/camera, AA {aa}, rows y%{cstep}==0 ({cpu.shape[0]} rows), {cs['rays']} rays in {cdt:.2f} s on {threads} threads; "
+                                      "CPU restatement of the reference algorithm (oracle/), not the Rust reference"}}
+    log(f"{tag}: {ms:.3f} ms per frame")
+    return out
+
+
+def other_configs(args, rl, np, torch, dev):
+    """BASELINE configs[2..4] on this GPU, after the headline loop: bounded (about two minutes), each entry with its own check, roofline figures and
+    CPU sample.  configs[3] at its stated 512 spp; configs[4] at --cfg5-spp (256; its stated 4096 spp take two minutes per frame)."""
+    import gzip
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("rl_oracle")
+    try:
+        threads = min(oracle.hardware_threads(), len(os.sched_getaffinity(0)))
+    except AttributeError:
+        threads = oracle.hardware_threads()
+    t_begin = time.perf_counter()
+
+    def log(msg):  # progress on stderr: a silent multi-minute run looks hung to the launcher
+        print(f"[bench configs {time.perf_counter() - t_begin:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+    G = os.path.join(ROOT, "tests", "golden")
+    which = [c.strip() for c in args.configs.split(",") if c.strip()]
+    res = []
+    if "cfg3" in which:
+        w = rl.RtcWorld.test_obj_scene(open(os.path.join(G, "teapot-low.obj"), "rb").read(), 1920, 1080)
+        res.append(bench_rtc_config(rl, oracle, np, torch, dev, w, 1, 100, threads, "cfg3_aa1", log))
+        res.append(bench_rtc_config(rl, oracle, np, torch, dev, w, 8, 5, threads, "cfg3_aa8", log))
+        del w
+    if "cfg4" in which or "cfg5" in which:
+        from PIL import Image
+        tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
+        obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
+    if "cfg4" in which:
+        w = rl.World.cow_scene(obj, tex)
+        p = w.params
+        p.aspect_ratio, p.image_width, p.samples_per_pixel = 16.0 / 9.0, 3840, args.cfg4_spp
+        res.append(bench_rtiow_config(rl, oracle, np, torch, dev,
+                                      f"RTIOW examples/cow.rs scene (5856 textured triangles under scale/rotate_y/translate + 6 quads), 3840x2160, {p.samples_per_pixel} spp, depth {p.max_depth}, on ONE GPU",
+                                      "cfg4", "configs[3]", w, p, threads, 8, 8.0, 16, log))
+        del w
+    if "cfg5" in which:
+        c0 = time.perf_counter()
+        w = rl.World.stress_scene(1000, 2, obj, tex, device_bvh=True)
+        build_s = time.perf_counter() - c0
+        log(f"cfg5: scene built in {build_s:.1f} s")
+        p = w.params
+        p.samples_per_pixel = args.cfg5_spp
+        e = bench_rtiow_config(rl, oracle, np, torch, dev,
+                               f"1,000,000 random spheres + 93,696-triangle mesh (DESIGN.md section 8), 3840x2160, {p.samples_per_pixel} spp (BASELINE: 4096), depth {p.max_depth}, on ONE GPU",
+                               "cfg5", "configs[4]", w, p, threads, 8, 8.0, 48, log)
+        e["scene_build_s"] = build_s
+        res.append(e)
+        del w
+    log("done")
+    return res
 
 
 def main():
@@ -329,6 +540,9 @@ def main():
                                    "sample": f"same scene/camera {W}x{H} depth {args.depth}: rows y%{cstep}==0 ({rl.api.rows_for(H, 0, cstep)} rows), "
                                              f"{cspp} spp, {cst['rays']} rays in {cdt:.1f} s on {threads} threads (one task per pixel); CPU restatement of the "
                                              "reference algorithm (oracle/, -O3 -ffp-contract=off), not the Rust reference"}
+        if world_size == 1 and not args.inprocess and args.emulate_shard <= 1 and args.configs:
+            del shard, counting_frame
+            out["configs"] = other_configs(args, rl, np, torch, dev)
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.destroy_process_group()
