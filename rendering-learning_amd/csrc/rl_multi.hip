@@ -76,6 +76,14 @@ void drop_comms() {
     if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
   g_rccl.comms.clear();
 }
+}  // namespace
+namespace rl {
+void drop_multi_state() {  // rl_init / rl_shutdown: communicators never outlive the device contexts they were built on
+  drop_comms();
+  g_emulated = false;
+}
+}  // namespace rl
+namespace {
 
 // out[r][x][c] = gathered[r % G][r / G][x][c]: the rows of rank g sit compact in slot g of the gather buffer
 __global__ void deinterleave_rows(const double *gathered, double *out, uint32_t H, uint32_t row_vals, uint32_t G, uint64_t slot_vals) {
@@ -90,7 +98,12 @@ __global__ void deinterleave_rows(const double *gathered, double *out, uint32_t 
 template <class F>
 int render_multi(const rl_scene *scene, uint32_t W, uint32_t H, void *d_out0, rl_stats *st, F render_shard) {
   const int G = n_contexts();
-  if (G == 1 || scene->replicas.empty()) {  // one GPU: the single-device path, straight into the caller's buffer
+  // a scene created under another rl_init / rl_init_multi holds buffers on device contexts that are gone (or never were):
+  // refuse it rather than render on one GPU silently or touch a device context 0 no longer points at
+  if (G > 1 && (int)scene->replicas.size() != G) return set_err_public(RL_E_INVALID, "scene was created before rl_init_multi: recreate it so that every device holds a replica");
+  if (G == 1 && (!scene->replicas.empty() || scene->ctx != 0 || scene->device != context(0).device))
+    return set_err_public(RL_E_INVALID, "scene was created under another rl_init / rl_init_multi: recreate it");
+  if (G == 1) {  // one GPU: the single-device path, straight into the caller's buffer
     int rc = use_context(0);
     if (rc != RL_OK) return rc;
     rc = render_shard(scene, 0, 1, d_out0, context(0).stream, st != nullptr);
@@ -98,7 +111,6 @@ int render_multi(const rl_scene *scene, uint32_t W, uint32_t H, void *d_out0, rl
     if (st) return collect_stats(scene, context(0).stream, st);
     return RL_OK;
   }
-  if ((int)scene->replicas.size() != G) return set_err_public(RL_E_INVALID, "scene was created before rl_init_multi: recreate it so that every device holds a replica");
   const uint32_t max_rows = (H + (uint32_t)G - 1) / (uint32_t)G;
   const uint64_t row_vals = (uint64_t)W * 3, slot_vals = (uint64_t)max_rows * row_vals;
   if (row_vals >= 0xFFFFFFFFull) return set_err_public(RL_E_INVALID, "image too wide");
@@ -119,6 +131,13 @@ int render_multi(const rl_scene *scene, uint32_t W, uint32_t H, void *d_out0, rl
       r->shard_bytes = need;
     }
   }
+  // back-to-back asynchronous frames: the previous frame's de-interleave (stream 0) still reads the gather slots that this frame's
+  // peer copies (stream g) will overwrite, and nothing else orders stream g behind it
+  if (root->ev_gather_read_valid)
+    for (int g = 1; g < G; g++) {
+      if ((rc = use_context(g)) != RL_OK) return rc;
+      HIP_TRY(hipStreamWaitEvent(context(g).stream, root->ev_gather_read, 0));
+    }
   // render: rank g takes rows g, g+G, ... on its own stream; nothing below waits on the host
   for (int g = 0; g < G && (uint32_t)g < H; g++) {  // more GPUs than image rows: the surplus ones have nothing to render
     if ((rc = use_context(g)) != RL_OK) return rc;
@@ -156,6 +175,9 @@ int render_multi(const rl_scene *scene, uint32_t W, uint32_t H, void *d_out0, rl
   hipLaunchKernelGGL(deinterleave_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, context(0).stream, root->d_shard, (double *)d_out0, H, (uint32_t)row_vals,
                      (uint32_t)G, slot_vals);
   HIP_TRY(hipGetLastError());
+  if (!root->ev_gather_read) HIP_TRY(hipEventCreateWithFlags(&root->ev_gather_read, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(root->ev_gather_read, context(0).stream));
+  root->ev_gather_read_valid = true;
   if (!st) return RL_OK;
   std::memset(st, 0, sizeof *st);
   int worst = RL_OK;

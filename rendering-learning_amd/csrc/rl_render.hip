@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -39,14 +40,70 @@ bool g_ready = false;
 std::vector<DevCtx> g_ctx;  // [0] is the device rl_init chose; rl_init_multi appends the others
 int g_cus = 0;
 size_t g_lds_max = 65536;
-int g_rtiow_variant = 0;  // 0 = automatic; see RL_RTIOW_KERNEL in rtiow_render_launch
-bool g_lpt = true;        // cost-sorted two-phase render (RL_LPT=0 disables; A/B only)
-bool g_coop_small = true;  // small frames through the cooperative kernel (RL_COOP=0 disables; A/B only)
-// work stealing on small shards: used when the shard has at most g_steal_max_fill x as many pixels as the GPU has lanes (RL_STEAL=<fill>, 0 = off)
-double g_steal_max_fill = 3.0;
+// Every RL_* environment switch (A/B and debugging only: DESIGN.md section 3.6) is read ONCE, by rl_init; the render path reads this struct.
+struct Switches {
+  int rtiow_variant = 0;         // RL_RTIOW_KERNEL (0 = automatic)
+  bool lpt = true;               // RL_LPT=0: single launch instead of the cost-sorted two-phase render
+  bool coop_small = true;        // RL_COOP=0: small frames through the wave-scheduled kernel instead of the cooperative one
+  double steal_max_fill = 3.0;   // RL_STEAL=<pixels per lane> (0 = off): work stealing on small shards
+  bool fast_traversal = true;    // RL_FAST=0: counter-free renders use the reference-order kernels too
+  bool tune_set = false;         // RL_TUNE="steps,floor16[,batch,fill]"
+  unsigned tune[4] = {24, 6, 24, 40};
+  unsigned blocks_cap = 0;       // RL_BLOCKS
+  int coop_mode = -1;            // RL_COOP_MODE
+  int general_regs = 512;        // RL_GENERAL_REGS (256 / 768: experimental library only)
+  bool fastg512 = false;         // RL_FASTG512 (experimental library only)
+  int general_nt = 512;          // RL_GENERAL_NT (768: experimental library only)
+  double thin_permille = 0.0, prio_permille = 0.0;  // RL_THIN / RL_PRIO (experimental library only)
+  int thin_shift = 2;            // RL_THIN_SHIFT
+  bool rtc_force_full = false;   // RL_RTC_FORCE_FULL
+  int rtc_full_regs = 768;       // RL_RTC_FULL_REGS (256 / 512: experimental library only)
+} g_sw;
 unsigned long long g_last_slow_traces = 0;
-bool g_fast_debug_stats = false;  // tools only: counting renders run the fast kernel too (counters are then NOT the reference's)
-bool g_fast_traversal = true;  // counter-free renders of LDS-sized sphere scenes use the fast traversal (RL_FAST=0 disables; A/B only)
+bool g_fast_debug_stats = false;  // tools only (experimental library): counting renders run the fast kernel too (counters are then NOT the reference's)
+
+void read_switches() {
+  Switches w;
+  if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
+    std::string sv(v);
+    w.rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : sv == "coop" ? 1033 : 0;
+  }
+  if (const char *v = std::getenv("RL_LPT")) w.lpt = std::string(v) != "0";
+  if (const char *v = std::getenv("RL_COOP")) w.coop_small = std::string(v) != "0";
+  if (const char *v = std::getenv("RL_STEAL")) w.steal_max_fill = std::atof(v);
+  if (const char *v = std::getenv("RL_FAST")) w.fast_traversal = std::string(v) != "0";
+  if (const char *t = std::getenv("RL_TUNE")) {
+    unsigned a = 16, b = 12, c = 24, d = 40;
+    int nf = std::sscanf(t, "%u,%u,%u,%u", &a, &b, &c, &d);
+    if (nf >= 2) w.tune[0] = a, w.tune[1] = b, w.tune_set = true;
+    if (nf >= 3) w.tune[2] = c;
+    if (nf >= 4) w.tune[3] = d;
+  }
+  if (const char *v = std::getenv("RL_BLOCKS")) w.blocks_cap = (unsigned)std::atoi(v);
+  if (const char *v = std::getenv("RL_COOP_MODE")) w.coop_mode = std::atoi(v);
+  if (const char *v = std::getenv("RL_GENERAL_REGS")) w.general_regs = std::atoi(v);
+  w.fastg512 = std::getenv("RL_FASTG512") != nullptr;
+  if (const char *v = std::getenv("RL_GENERAL_NT")) w.general_nt = std::atoi(v);
+  if (const char *v = std::getenv("RL_THIN")) w.thin_permille = std::atof(v);
+  if (const char *v = std::getenv("RL_PRIO")) w.prio_permille = std::atof(v);
+  if (const char *v = std::getenv("RL_THIN_SHIFT")) w.thin_shift = std::min(6, std::max(1, std::atoi(v)));
+  w.rtc_force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;
+  if (const char *v = std::getenv("RL_RTC_FULL_REGS")) w.rtc_full_regs = std::atoi(v);
+  g_sw = w;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (kernel, device): set it when a launch needs more than any before it did
+std::map<std::pair<const void *, int>, size_t> g_lds_attr;
+int ensure_lds_attr(const void *kern, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  size_t &have = g_lds_attr[{kern, dev}];
+  if (lds <= have) return 0;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+  have = lds;
+  return 0;
+}
 
 int set_err(int code, const std::string &m) {
   g_err = m;
@@ -166,21 +223,16 @@ int rl_init(int device) {
   if (e != hipSuccess || n <= 0) return set_err(RL_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
   if (device >= n) return set_err(RL_E_INVALID, "device index out of range");
   if (device < 0) HIP_TRY(hipGetDevice(&device));
+  rl::drop_multi_state();
   int rc = rl::set_contexts({device});
   if (rc != RL_OK) return rc;
-  if (const char *v = std::getenv("RL_RTIOW_KERNEL")) {
-    std::string sv(v);
-    g_rtiow_variant = sv == "v1" ? 1 : sv == "general" ? 2 : sv == "wavefront" ? 3 : sv == "wavegeneral" ? 4 : sv == "pool" ? 5 : sv == "pool256" ? 6 : sv == "wave2" ? 7 : sv == "wave256" ? 256 : sv == "wave512" ? 512 : sv == "wave768" ? 768 : sv == "wave1024" ? 1024 : sv == "wave1024ops" ? 1025 : sv == "wave1024guard" ? 1027 : sv == "wave1024fast" ? 1029 : sv == "coop" ? 1033 : 0;
-  }
-  if (const char *v = std::getenv("RL_LPT")) g_lpt = std::string(v) != "0";
-  if (const char *v = std::getenv("RL_COOP")) g_coop_small = std::string(v) != "0";
-  if (const char *v = std::getenv("RL_STEAL")) g_steal_max_fill = std::atof(v);
-  if (const char *v = std::getenv("RL_FAST")) g_fast_traversal = std::string(v) != "0";
+  read_switches();
   g_ready = true;
   return RL_OK;
 }
 
 void rl_shutdown(void) {
+  rl::drop_multi_state();
   std::lock_guard<std::mutex> lk(g_mu);
   for (DevCtx &c : g_ctx)
     if (c.stream && hipSetDevice(c.device) == hipSuccess) hipStreamDestroy(c.stream), hipEventDestroy(c.ev);
@@ -216,6 +268,7 @@ static void destroy_one(rl_scene *s) {
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->ev_done) hipEventDestroy(s->ev_done);
+  if (s->ev_gather_read) hipEventDestroy(s->ev_gather_read);
   delete s;
 }
 
@@ -407,7 +460,7 @@ static int build_host_rtiow(const rl_rtiow_scene_desc *desc, std::shared_ptr<con
 // Device half: one replica on device context `ctx` (the current device must already be that context's)
 static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx) {
   rl_scene *s = new rl_scene();
-  s->kind = 1, s->ctx = ctx, s->hrt = H;
+  s->kind = 1, s->ctx = ctx, s->device = g_ctx[(size_t)ctx].device, s->hrt = H;
   const RtiowProgram &rt = H->rt;
   int rc = RL_OK;
   if ((rc = upload(rt.ops, &s->d_ops)) || (rc = upload(rt.spheres, &s->d_spheres)) || (rc = upload(rt.sphere_material, &s->d_sphere_material)) ||
@@ -608,14 +661,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
   P.out = (double *)d_out;
   P.k8u = 8.8817841970012523e-16;
-  P.tune[0] = 24, P.tune[1] = 6, P.tune[2] = 24, P.tune[3] = 40;
-  if (const char *t = std::getenv("RL_TUNE")) {  // "iters,floor16[,refill_batch,refill_fill]" (A/B only)
-    unsigned a = 16, b = 12, c = 24, d = 40;
-    int nf = std::sscanf(t, "%u,%u,%u,%u", &a, &b, &c, &d);
-    if (nf >= 2) P.tune[0] = a, P.tune[1] = b;
-    if (nf >= 3) P.tune[2] = c;
-    if (nf >= 4) P.tune[3] = d;
-  }
+  P.tune[0] = g_sw.tune[0], P.tune[1] = g_sw.tune[1], P.tune[2] = g_sw.tune[2], P.tune[3] = g_sw.tune[3];
   P.pix_rays = want_stats ? scene->d_pix_rays : nullptr;
 
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
@@ -627,27 +673,28 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     if (per_cu < 1) per_cu = 1;
     if (per_cu * nt > 2048) per_cu = 2048 / nt;
     if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
-    if (const char *b = std::getenv("RL_BLOCKS")) {  // A/B only
-      unsigned nb = (unsigned)std::atoi(b);
-      if (nb >= 1 && nb < blocks) blocks = nb;
-    }
-    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;  // A/B only
+    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
     HIP_TRY(hipGetLastError());
     return RL_OK;
   };
-  // kernel variant: wave-scheduled state machine (default) or the plain nested-loop kernel ("v1");
-  // RL_RTIOW_KERNEL=v1|wave512|wave768|wave1024 selects one for A/B runs (same results, different schedule)
-  int variant = g_rtiow_variant;
+  // ---- kernel variant.  The PRODUCT library carries, for sphere-only worlds, the four layouts the automatic choice below can reach
+  // (1029 fast traversal / 1027 guarded compact ops / 1025 linked ops in LDS / 1024 scene through L2), the cooperative kernel (1033) and
+  // the nested-loop all-primitives kernel (2: the A/B reference the tests compare against); for general worlds 1031 (fast traversal) and
+  // 4 (reference order).  Every other instantiation (wave256 / 512 / 768, whole-scene-in-LDS layouts, v1, other register budgets,
+  // pool / wave2 / wavefront) is A/B material and lives in librl_render_exp.so (make exp).
+  int variant = g_sw.rtiow_variant;
   bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
   // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: the reference-order kernels evaluate it (the
   // wave-scheduled one as a scope of the threaded program, the nested-loop one by recursion: RL_RTIOW_KERNEL=general); no fast traversal
   if (rt.has_media && variant != 2) variant = 4;
 #ifndef RL_EXPERIMENTAL
-  if (variant == 3 || variant == 5 || variant == 6 || variant == 7) return set_err(RL_E_UNSUPPORTED, "experimental kernel variants live in librl_render_exp.so only");
+  if (variant == 1 || variant == 3 || variant == 5 || variant == 6 || variant == 7 || variant == 256 || variant == 512 || variant == 768)
+    return set_err(RL_E_UNSUPPORTED, "this kernel variant is A/B material and lives in librl_render_exp.so only (make -C rendering-learning_amd/csrc exp)");
 #endif
   // 1031 = the FAST traversal for general scenes (rl_rtiow_fastgen.h): counter-free renders only, like 1029
-  const bool fits_fastg = general && H.fg.ok && (!want_stats) && g_fast_traversal;
+  const bool fits_fastg = general && H.fg.ok && (!want_stats) && g_sw.fast_traversal;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
   else if ((variant == 0 || variant == 1031) && fits_fastg) variant = 1031;
   else if (general || variant == 4 || variant == 1031) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
@@ -669,24 +716,23 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // its box / sphere test counts are not the reference's, so a render that asks for rl_stats runs the counting kernel (1027)
   const size_t fast_bytes = ((size_t)P.n_fast_inner * sizeof(FastNode) + 2 * (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
   const bool fits_fast = fits_compact && H.fast_root != FAST_NONE && (!want_stats || g_fast_debug_stats) && (size_t)16 * 1024 * sizeof(unsigned long long) + fast_bytes <= g_lds_max &&
-                         g_fast_traversal;
+                         g_sw.fast_traversal;
+  const bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
   if (variant == 1029 && (general || !fits_fast)) variant = 0;
   if (variant == 1033 && (general || !fits_fast || want_stats)) variant = 0;  // cooperative kernel: the fast structure's scenes, counter-free renders
   if (variant == 1027 && (general || !fits_compact)) variant = 0;
-  if (variant == 1025 && (general || (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) > g_lds_max)) variant = 0;
+  if (variant == 1025 && (general || !fits_ops)) variant = 0;
   if (variant == 7 && (general || (size_t)8 * 1024 * sizeof(unsigned long long) + scene_bytes > g_lds_max)) variant = 0;  // two-context kernel needs the scene in LDS
   if ((variant == 5 || variant == 6) && (general || (size_t)(variant == 5 ? 512 : 256) * 192 + scene_bytes > g_lds_max)) variant = 0;  // pool kernel needs the scene in LDS
   if (variant == 0 && !general) {
-    // automatic: 4 waves per SIMD with the ChaCha rings and the linked ops in LDS (spheres through L2) when that fits;
-    // else 3 (or 2) waves per SIMD with the whole scene in LDS; else 4 waves per SIMD reading everything from HBM / L2
-    auto fits = [&](int nt) { return (size_t)16 * nt * sizeof(unsigned long long) + scene_bytes <= g_lds_max; };
-    bool fits_ops = (size_t)16 * 1024 * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp) <= g_lds_max;
-    variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : fits(768) ? 768 : fits(512) ? 512 : 1024;
+    // automatic: 4 waves per SIMD (1024 lanes per CU, 128 KB of ChaCha rings) with, in LDS next to the rings, the fast tree / the
+    // guarded compact ops / the linked ops — whichever fits first — and otherwise the whole scene read through L2
+    variant = fits_fast ? 1029 : fits_compact ? 1027 : fits_ops ? 1025 : 1024;
     // Small frames (at most 10 pixels per wave the GPU can hold) are pure latency: every pixel's sample chain runs alone, and the
     // cooperative one-wave-per-pixel kernel advances a chain in 3.9 us per ray instead of ~22 (rl_rtiow_coop.h).  Measured at 1024 spp:
     // 2.2 k pixels 184 -> 30 ms, 9 k 248 -> 68, 20 k 267 -> 109, 37 k 264 -> 167, 90 k 291 -> 380 (tools/coop_check.py); from ~40 k
     // pixels on the wave-scheduled kernel with work stealing is as fast or faster (37 k: 173 ms, 90 k: 170 ms; tools/steal_ab.py).
-    if (variant == 1029 && !want_stats && g_coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 10u) variant = 1033;
+    if (variant == 1029 && !want_stats && g_sw.coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 10u) variant = 1033;
   }
   bool steal = false;  // set for the resume launch of a small shard (variant 1029)
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
@@ -701,50 +747,52 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     uint32_t cap = (uint32_t)g_cus * (16 / NW);  // 4 waves per SIMD at 128 VGPRs
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return RL_OK;
-    static const int coop_mode = std::getenv("RL_COOP_MODE") ? std::atoi(std::getenv("RL_COOP_MODE")) : -1;  // A/B: 0 L2 boxes, 128 VGPRs; 1 L2 boxes; 2 boxes in registers
     // the lowest latency (boxes in registers: 3.3 us per ray, two waves per SIMD) while every pixel gets a wave at once; the register
-    // budget of four waves per SIMD (boxes from L2: 4.0 us per ray, +25 % throughput) for larger frames
-    int mode = coop_mode >= 0 ? coop_mode : (n_pixels <= (uint32_t)g_cus * 8u ? 2 : 0);
-    if (mode == 0) {
-      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((rtiow_coop_kernel<NW, false, 1024>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
-    } else if (mode == 2) {
-      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, true, NW * 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // budget of four waves per SIMD (boxes from L2: 4.0 us per ray, +25 % throughput) for larger frames.  RL_COOP_MODE forces one (A/B).
+    int mode = g_sw.coop_mode >= 0 ? g_sw.coop_mode : (n_pixels <= (uint32_t)g_cus * 8u ? 2 : 0);
+    if (mode == 2) {
+      if (ensure_lds_attr((const void *)rtiow_coop_kernel<NW, true, NW * 64>, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute failed");
       hipLaunchKernelGGL((rtiow_coop_kernel<NW, true, NW * 64>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
-    } else {
-      HIP_TRY(hipFuncSetAttribute((const void *)rtiow_coop_kernel<NW, false, NW * 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef RL_EXPERIMENTAL
+    } else if (mode == 1) {  // L2 boxes at the register budget of two waves per SIMD
+      if (ensure_lds_attr((const void *)rtiow_coop_kernel<NW, false, NW * 64>, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute failed");
       hipLaunchKernelGGL((rtiow_coop_kernel<NW, false, NW * 64>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
+#endif
+    } else {
+      if (ensure_lds_attr((const void *)rtiow_coop_kernel<NW, false, 1024>, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute failed");
+      hipLaunchKernelGGL((rtiow_coop_kernel<NW, false, 1024>), dim3(blocks), dim3(NW * 64), lds, stream, P, C);
     }
     HIP_TRY(hipGetLastError());
     return RL_OK;
   };
   auto launch_variant = [&]() -> int {
     int rc;
-#define RL_LAUNCH_WAVE(NT)                                                                                              \
-  {                                                                                                                     \
-    size_t rb = (size_t)16 * NT * sizeof(unsigned long long);                                                           \
-    bool in_lds = rb + scene_bytes <= g_lds_max;                                                                        \
-    if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, 1, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, 1, false>, NT, rb, true); \
-    else rc = want_stats ? launch(rtiow_wave_kernel<NT, 0, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 0, false>, NT, rb, false);   \
-  }
     if (variant == 2) {
       constexpr int NT = 256;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       // register budget of two waves per SIMD (256 registers instead of 256 + 151): cornell_smoke 309 -> 493 Mrays/s, final_scene 170 -> 219
-      // (three waves: 390 / 182).  RL_GENERAL_REGS=256|768 selects the others (A/B).
-      static const int regs = std::getenv("RL_GENERAL_REGS") ? std::atoi(std::getenv("RL_GENERAL_REGS")) : 512;
-      if (regs == 512) rc = want_stats ? launch(rtiow_general_kernel<NT, true, 512>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 512>, NT, rb, false);
-      else if (regs == 768) rc = want_stats ? launch(rtiow_general_kernel<NT, true, 768>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 768>, NT, rb, false);
-      else rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+      // (three waves: 390 / 182).  RL_GENERAL_REGS=256|768 selects the others (experimental library).
+#ifdef RL_EXPERIMENTAL
+      if (g_sw.general_regs == 768) rc = want_stats ? launch(rtiow_general_kernel<NT, true, 768>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 768>, NT, rb, false);
+      else if (g_sw.general_regs == 256) rc = want_stats ? launch(rtiow_general_kernel<NT, true>, NT, rb, false) : launch(rtiow_general_kernel<NT, false>, NT, rb, false);
+      else
+#endif
+        rc = want_stats ? launch(rtiow_general_kernel<NT, true, 512>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 512>, NT, rb, false);
     } else if (variant == 1031) {  // rings + the traversal stacks in LDS
       // four steps per scheduling round (a step is an Infinity Cache / L2 round trip here, not an LDS one: lanes that fall out of TRAV
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
-      if (!std::getenv("RL_TUNE")) P.tune[0] = 4;
+      if (!g_sw.tune_set) P.tune[0] = 4;
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      if (trans || std::getenv("RL_FASTG512")) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
+      if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
         constexpr int NT = 512, SD = 40;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
-        rc = trans ? launch(rtiow_fast_general_kernel<NT, SD, true>, NT, rb, false) : launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+        rc = launch(rtiow_fast_general_kernel<NT, SD, true>, NT, rb, false);
+#ifdef RL_EXPERIMENTAL
+      } else if (g_sw.fastg512) {
+        constexpr int NT = 512, SD = 40;
+        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        rc = launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+#endif
       } else {  // 768 lanes per CU (3 waves per SIMD hide more of the node-fetch latency), 20-entry stacks: 208 B of LDS per lane
         constexpr int NT = 768, SD = 20;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
@@ -753,19 +801,21 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     } else if (variant == 4) {
       // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of
       // scenes that have Noise textures or Image textures on spheres).  At 768 lanes (168 VGPRs) the spills land in the TRAV
-      // loop and cost 2.3x (measured, cfg 4: 1101 vs 465 Mrays/s).  RL_GENERAL_NT=768 overrides (A/B only).
+      // loop and cost 2.3x (measured, cfg 4: 1101 vs 465 Mrays/s; RL_GENERAL_NT=768 in the experimental library).
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      int gnt = 512;
-      if (const char *e = std::getenv("RL_GENERAL_NT")) gnt = std::atoi(e);
-      size_t rb = (size_t)16 * gnt * sizeof(unsigned long long);
+      size_t rb = (size_t)16 * 512 * sizeof(unsigned long long);
       if (rt.has_media) {  // + the parked HitRecord of a medium scope: 96 B of LDS per lane
         size_t mb = (size_t)512 * (16 + MEDIA_SAVE_WORDS) * sizeof(unsigned long long);
         if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true, true>, 512, mb, false) : launch(rtiow_wave_general_kernel<512, true, false, true>, 512, mb, false);
         else rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true, true>, 512, mb, false) : launch(rtiow_wave_general_kernel<512, false, false, true>, 512, mb, false);
-      } else if (trans && gnt == 768) rc = want_stats ? launch(rtiow_wave_general_kernel<768, true, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, true, false>, 768, rb, false);
-      else if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, true, false>, 512, rb, false);
-      else if (gnt == 512) rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, false, false>, 512, rb, false);
-      else rc = want_stats ? launch(rtiow_wave_general_kernel<768, false, true>, 768, rb, false) : launch(rtiow_wave_general_kernel<768, false, false>, 768, rb, false);
+#ifdef RL_EXPERIMENTAL
+      } else if (g_sw.general_nt == 768) {
+        size_t rb7 = (size_t)16 * 768 * sizeof(unsigned long long);
+        if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<768, true, true>, 768, rb7, false) : launch(rtiow_wave_general_kernel<768, true, false>, 768, rb7, false);
+        else rc = want_stats ? launch(rtiow_wave_general_kernel<768, false, true>, 768, rb7, false) : launch(rtiow_wave_general_kernel<768, false, false>, 768, rb7, false);
+#endif
+      } else if (trans) rc = want_stats ? launch(rtiow_wave_general_kernel<512, true, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, true, false>, 512, rb, false);
+      else rc = want_stats ? launch(rtiow_wave_general_kernel<512, false, true>, 512, rb, false) : launch(rtiow_wave_general_kernel<512, false, false>, 512, rb, false);
 #ifdef RL_EXPERIMENTAL
     } else if (variant == 5) {
       constexpr int NT = 512;
@@ -777,14 +827,27 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     } else if (variant == 6) {
       constexpr int NT = 256;
       rc = want_stats ? launch(rtiow_pool_kernel<NT, true>, NT, (size_t)NT * 192, true) : launch(rtiow_pool_kernel<NT, false>, NT, (size_t)NT * 192, true);
-#endif
-    } else if (variant == 1) {
+    } else if (variant == 1) {  // the first correct kernel: nested loops, exact divisions
       constexpr int NT = 1024;
       size_t rb = (size_t)8 * NT * sizeof(unsigned long long);
       bool in_lds = rb + scene_bytes <= g_lds_max;
       if (in_lds) rc = want_stats ? launch(rtiow_spheres_kernel<NT, true, true>, NT, rb, true) : launch(rtiow_spheres_kernel<NT, true, false>, NT, rb, true);
       else rc = want_stats ? launch(rtiow_spheres_kernel<NT, false, true>, NT, rb, false) : launch(rtiow_spheres_kernel<NT, false, false>, NT, rb, false);
-    } else if (variant == 1025) {  // 4 waves per SIMD: rings + linked ops in LDS, spheres read from L2
+#define RL_LAUNCH_WAVE(NT)                                                                                              \
+  {                                                                                                                     \
+    size_t rb = (size_t)16 * NT * sizeof(unsigned long long);                                                           \
+    bool in_lds = rb + scene_bytes <= g_lds_max;                                                                        \
+    if (in_lds) rc = want_stats ? launch(rtiow_wave_kernel<NT, 1, true>, NT, rb, true) : launch(rtiow_wave_kernel<NT, 1, false>, NT, rb, true); \
+    else rc = want_stats ? launch(rtiow_wave_kernel<NT, 0, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 0, false>, NT, rb, false);   \
+  }
+    } else if (variant == 768) RL_LAUNCH_WAVE(768)
+    else if (variant == 256) RL_LAUNCH_WAVE(256)
+    else if (variant == 512) RL_LAUNCH_WAVE(512)
+#undef RL_LAUNCH_WAVE
+#else
+    }
+#endif
+    else if (variant == 1025) {  // 4 waves per SIMD: rings + linked ops in LDS, spheres read from L2
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + (size_t)P.n_ops * sizeof(DevOp);
       rc = want_stats ? launch(rtiow_wave_kernel<NT, 2, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 2, false>, NT, rb, false);
@@ -804,19 +867,21 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;
       // leave a TRAV round when fewer than a quarter of the lanes it started with are still walking (the counting kernels: 3/8): with
       // pair nodes and inline misses the walks are short and uneven — +2.1 % (6596 -> 6734 Mrays/s; 24,2: 6740; 24,1: 6586; tools: RL_TUNE)
-      if (!std::getenv("RL_TUNE")) P.tune[1] = 4;
-      // <.., 4, true> only under rl_debug_fast_stats (tools/sched.py): scheduler occupancy of the fast kernel; its box / sphere counts are its own
+      if (!g_sw.tune_set) P.tune[1] = 4;
       if (steal) rc = launch(rtiow_wave_kernel<NT, 4, false, true>, NT, rb, false);
-      else rc = want_stats ? launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
+#ifdef RL_EXPERIMENTAL  // <.., 4, true> only under rl_debug_fast_stats (tools/sched.py): scheduler occupancy of the fast kernel; its box / sphere counts are its own
+      else if (want_stats) rc = launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false);
+#endif
+      else rc = launch(rtiow_wave_kernel<NT, 4, false>, NT, rb, false);
     } else if (variant == 1027) {  // 4 waves per SIMD: rings + compact guarded ops in LDS, spheres read from L2
       constexpr int NT = 1024;
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + compact_bytes;
       rc = want_stats ? launch(rtiow_wave_kernel<NT, 3, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 3, false>, NT, rb, false);
-    } else if (variant == 768) RL_LAUNCH_WAVE(768)
-    else if (variant == 1024) RL_LAUNCH_WAVE(1024)
-    else if (variant == 256) RL_LAUNCH_WAVE(256)
-    else RL_LAUNCH_WAVE(512)
-#undef RL_LAUNCH_WAVE
+    } else {  // 1024: everything through L2 (sphere-only worlds too large for LDS)
+      constexpr int NT = 1024;
+      size_t rb = (size_t)16 * NT * sizeof(unsigned long long);
+      rc = want_stats ? launch(rtiow_wave_kernel<NT, 0, true>, NT, rb, false) : launch(rtiow_wave_kernel<NT, 0, false>, NT, rb, false);
+    }
     return rc;
   };
   P.sample_begin = 0, P.sample_end = cam->samples_per_pixel, P.resume = 0;
@@ -825,7 +890,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // pixel and records each 8x8 tile's ray count; the tiles are then sorted by cost and the remaining samples are
   // rendered expensive-tiles-first (LPT), so the tail of the launch holds cheap pixels only.  Pixels are resumed
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
-  const bool lpt_enabled = g_lpt;
+  const bool lpt_enabled = g_sw.lpt;
   const uint32_t lpt_first = 8;
   bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 1031 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
@@ -864,7 +929,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
-    if (variant == 1029 && !want_stats && g_steal_max_fill > 0.0 && (double)npix <= g_steal_max_fill * (double)g_cus * 1024.0) {
+    if (variant == 1029 && !want_stats && g_sw.steal_max_fill > 0.0 && (double)npix <= g_sw.steal_max_fill * (double)g_cus * 1024.0) {
       // small shard: waves that run out of pixels take over pixels other lanes are still rendering (rl_rtiow_coop.h rtiow_steal_loop)
       if (ms->steal_pix < npix) {
         hipFree(ms->d_steal_state), hipFree(ms->d_steal_n);
@@ -885,12 +950,9 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       // emulated 1/8 shard: 271 - 283 ms against 279 at best, slower when more than ~1 % of the tiles are thinned: the longest sample
       // chain's time is per-ray LATENCY (9.6 us for a pixel alone on the GPU, tools/lone_ray.py), which neither shortens
 #ifdef RL_EXPERIMENTAL
-      double permille = 0.0;
-      if (const char *e = std::getenv("RL_THIN")) permille = std::atof(e);
-      P.thin_tiles = (uint32_t)((double)ntiles * permille / 1000.0);
-      P.thin_shift = 2;
-      if (const char *e = std::getenv("RL_PRIO")) P.prio_tiles = (uint32_t)((double)ntiles * std::atof(e) / 1000.0);  // A/B
-      if (const char *e = std::getenv("RL_THIN_SHIFT")) P.thin_shift = (uint32_t)std::min(6, std::max(1, std::atoi(e)));
+      P.thin_tiles = (uint32_t)((double)ntiles * g_sw.thin_permille / 1000.0);
+      P.thin_shift = (uint32_t)g_sw.thin_shift;
+      P.prio_tiles = (uint32_t)((double)ntiles * g_sw.prio_permille / 1000.0);  // A/B
       uint64_t total = slots + (((uint64_t)P.thin_tiles * 64u) << P.thin_shift);
       if (total >= 0xFFFF0000ull) P.thin_tiles = 0;
 #endif
@@ -932,6 +994,8 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
   for (size_t g = 0; g < n; g++) {
     rl_scene *r = const_cast<rl_scene *>(scene->replicas.empty() ? scene : scene->replicas[g]);
     if (!r->async_pending) continue;
+    if (r->ctx < 0 || (size_t)r->ctx >= g_ctx.size() || g_ctx[(size_t)r->ctx].device != r->device)
+      return set_err(RL_E_INVALID, "scene belongs to a device context that no longer exists (created under another rl_init / rl_init_multi)");
     int rc = rl::use_context(r->ctx);
     if (rc != RL_OK) return rc;
     HIP_TRY(hipEventSynchronize(r->ev_done));
@@ -1079,12 +1143,18 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
   }
   return RL_OK;
 }
-void rl_debug_set_rtiow_variant(int v) { g_rtiow_variant = v; }
-void rl_debug_set_lpt(int on) { g_lpt = on != 0; }
-void rl_debug_set_coop(int on) { g_coop_small = on != 0; }
-void rl_debug_set_steal(double max_fill) { g_steal_max_fill = max_fill; }
-void rl_debug_set_fast_traversal(int on) { g_fast_traversal = on != 0; }
-void rl_debug_fast_stats(int on) { g_fast_debug_stats = on != 0; }
+void rl_debug_set_rtiow_variant(int v) { g_sw.rtiow_variant = v; }
+void rl_debug_set_lpt(int on) { g_sw.lpt = on != 0; }
+void rl_debug_set_coop(int on) { g_sw.coop_small = on != 0; }
+void rl_debug_set_steal(double max_fill) { g_sw.steal_max_fill = max_fill; }
+void rl_debug_set_fast_traversal(int on) { g_sw.fast_traversal = on != 0; }
+void rl_debug_fast_stats(int on) {  // the instrumented fast kernel <1024, 4, true> exists in the experimental library only
+#ifdef RL_EXPERIMENTAL
+  g_fast_debug_stats = on != 0;
+#else
+  (void)on;
+#endif
+}
 #ifdef RL_FASTG_VERIFY
 int rl_debug_fastg_verify(unsigned int *count, double *log768) {
   HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(rl::g_vcount), 4));
@@ -1259,7 +1329,7 @@ static void build_rtc_guards(RtcProgram &rc, std::vector<RtcGuard> &guards) {
 
 static rl_scene *upload_rtc(const std::shared_ptr<const HostRtc> &H, int ctx) {
   rl_scene *s = new rl_scene();
-  s->kind = 2, s->ctx = ctx, s->hrc = H;
+  s->kind = 2, s->ctx = ctx, s->device = g_ctx[(size_t)ctx].device, s->hrc = H;
   const RtcProgram &rc_ = H->rc;
   int rc = RL_OK;
   if ((!H->guards.empty() && (rc = upload(H->guards, &s->d_guards))) || (rc = upload(rc_.ops, &s->d_ops)) || (rc = upload(rc_.tris, &s->d_tris)) ||
@@ -1342,8 +1412,7 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
   uint64_t want = (total + NT - 1) / NT;
   uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
-  static const bool force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;  // A/B: triangle-only worlds through the full kernel
-  if (rc_.needs_full || force_full) {  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
+  if (rc_.needs_full || g_sw.rtc_force_full) {  // (RL_RTC_FORCE_FULL: A/B, triangle-only worlds through the full kernel)  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
     RtcFullParams F{};
     F.R = P;
     F.shapes = scene->d_shapes, F.csgs = scene->d_csgs, F.patterns = scene->d_patterns;
@@ -1351,10 +1420,12 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
     // register budget of three waves per SIMD (168 VGPRs; ~165 of the kernel's binary64 temporaries then live in scratch, at points that
     // run once per ray): measured 13.3 / 14.0 / 19.2 ms for 3 / 2 / 1 waves on the mirror scene at 1080p, 2.7 / 2.9 / 4.2 ms on the teapot
     // forced through this kernel.  RL_RTC_FULL_REGS=256|512 selects the other budgets (A/B).
-    static const int regs_for = std::getenv("RL_RTC_FULL_REGS") ? std::atoi(std::getenv("RL_RTC_FULL_REGS")) : 768;
-    if (regs_for == 512) hipLaunchKernelGGL((rtc_full_kernel<NT, 512>), dim3(blocks), dim3(NT), 0, stream, F);
-    else if (regs_for == 256) hipLaunchKernelGGL((rtc_full_kernel<NT, 256>), dim3(blocks), dim3(NT), 0, stream, F);
-    else hipLaunchKernelGGL((rtc_full_kernel<NT, 768>), dim3(blocks), dim3(NT), 0, stream, F);
+#ifdef RL_EXPERIMENTAL
+    if (g_sw.rtc_full_regs == 512) hipLaunchKernelGGL((rtc_full_kernel<NT, 512>), dim3(blocks), dim3(NT), 0, stream, F);
+    else if (g_sw.rtc_full_regs == 256) hipLaunchKernelGGL((rtc_full_kernel<NT, 256>), dim3(blocks), dim3(NT), 0, stream, F);
+    else
+#endif
+      hipLaunchKernelGGL((rtc_full_kernel<NT, 768>), dim3(blocks), dim3(NT), 0, stream, F);
   } else if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
   else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
   HIP_TRY(hipGetLastError());

@@ -43,6 +43,7 @@ struct HostRtc {
 struct rl_scene {
   int kind = 0;  // 1 = RTIOW, 2 = RTC
   int ctx = 0;   // index of the device context this replica lives on
+  int device = -1;  // ... and that context's HIP device ordinal at creation (a later rl_init may point context 0 elsewhere)
   std::shared_ptr<const rl::HostRtiow> hrt;
   std::shared_ptr<const rl::HostRtc> hrc;
   const rl::RtiowProgram &rt() const { return hrt->rt; }
@@ -100,6 +101,8 @@ struct rl_scene {
   // multi-GPU: this replica's row shard / on replica 0 the gather buffer [G][max_rows][W][3]
   double *d_shard = nullptr;
   size_t shard_bytes = 0;
+  hipEvent_t ev_gather_read = nullptr;  // replica 0: recorded behind the de-interleave kernel that reads the gather slots
+  bool ev_gather_read_valid = false;
   uint32_t *d_pix_rays = nullptr;  // debug (tools/): per-pixel ray counts of the last counting render
   void *exp = nullptr;             // experimental kernels' work buffers (rl_render.hip, RL_EXPERIMENTAL builds only)
 };
@@ -111,6 +114,7 @@ bool lib_ready();
 int n_contexts();
 DevCtx &context(int i);
 int use_context(int i);  // hipSetDevice(context(i).device)
+void drop_multi_state();  // rl_multi.hip: RCCL communicators + the emulation flag, dropped whenever the context list is rebuilt
 
 // Launch-only halves of the render entry points (rl_render.hip): enqueue everything on `stream`, never synchronise.  With
 // want_stats the caller finishes with collect_stats (which synchronises the stream).

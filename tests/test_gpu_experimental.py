@@ -17,7 +17,8 @@ def test_experimental_variants_equal_the_product_kernel(rl):
     st0 = {}
     a = cam.render(world, stats=st0).data
     try:
-        for v in (3, 5, 7):  # wavefront, pool, wave2
+        # wavefront, pool, wave2; the first correct kernel (v1: nested loops, exact divisions); the 3 / 2 / 1-waves layouts with the scene in LDS
+        for v in (3, 5, 7, 1, 768, 512, 256):
             rl.api.set_rtiow_variant(v)
             sv = {}
             assert np.array_equal(cam.render(world, stats=sv).data, a), v

@@ -130,9 +130,9 @@ def test_general_kernel_equals_wave_kernel_on_spheres(rl):
     st0 = {}
     a = cam.render(world, stats=st0).data
     try:
-        # 2 = nested-loop all-primitives kernel, 1 = nested-loop sphere kernel, 4 = wave-scheduled all-primitives kernel,
-        # 1025 = 1024 lanes with 64-byte ops (no guards), 768 / 512 / 256 = 3-waves layout, 1024 = scene in HBM
-        for v in (2, 1, 4, 1025, 1024, 768, 512, 256):
+        # 2 = nested-loop all-primitives kernel, 4 = wave-scheduled all-primitives kernel, 1027 = guarded compact ops in LDS (the
+        # counting renders' default), 1025 = 1024 lanes with 64-byte linked ops (no guards), 1024 = scene through L2
+        for v in (2, 4, 1027, 1025, 1024):
             rl.api.set_rtiow_variant(v)
             sv = {}
             img = cam.render(world, stats=sv).data
