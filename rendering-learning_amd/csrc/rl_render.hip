@@ -28,6 +28,7 @@
 #include "experimental/rl_rtiow_pool.h"
 #include "experimental/rl_rtiow_wave2.h"
 #include "experimental/rl_rtiow_wavefront.h"
+#include "experimental/rl_rtiow_wfg.h"
 #endif
 
 using namespace rl;
@@ -56,6 +57,7 @@ struct Switches {
   int general_nt = 512;          // RL_GENERAL_NT (768: experimental library only)
   double thin_permille = 0.0, prio_permille = 0.0;  // RL_THIN / RL_PRIO (experimental library only)
   int thin_shift = 2;            // RL_THIN_SHIFT
+  int wavefront = -1;            // RL_WAVEFRONT=1: general fast-traversal scenes in wavefront form (experimental library only)
   bool rtc_force_full = false;   // RL_RTC_FORCE_FULL
   int rtc_full_regs = 768;       // RL_RTC_FULL_REGS (256 / 512: experimental library only)
 } g_sw;
@@ -87,6 +89,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_THIN")) w.thin_permille = std::atof(v);
   if (const char *v = std::getenv("RL_PRIO")) w.prio_permille = std::atof(v);
   if (const char *v = std::getenv("RL_THIN_SHIFT")) w.thin_shift = std::min(6, std::max(1, std::atoi(v)));
+  if (const char *v = std::getenv("RL_WAVEFRONT")) w.wavefront = std::atoi(v);
   w.rtc_force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;
   if (const char *v = std::getenv("RL_RTC_FULL_REGS")) w.rtc_full_regs = std::atoi(v);
   g_sw = w;
@@ -269,6 +272,8 @@ static void destroy_one(rl_scene *s) {
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->ev_done) hipEventDestroy(s->ev_done);
   if (s->ev_gather_read) hipEventDestroy(s->ev_gather_read);
+  hipFree(s->d_wfg_pix), hipFree(s->d_wfg_ray), hipFree(s->d_wfg_q0), hipFree(s->d_wfg_q1), hipFree(s->d_wfg_qs), hipFree(s->d_wfg_ctl);
+  if (s->h_wfg) hipHostFree(s->h_wfg);
   delete s;
 }
 
@@ -630,6 +635,70 @@ static int render_wavefront(const rl_scene *scene, RtiowParams &P, uint32_t nrow
 
 #endif
 
+#ifdef RL_EXPERIMENTAL
+// Wavefront form of the general fast traversal (rl_rtiow_wfg.h): init, then PASSES of wfg_logic + wfg_trav until every pixel has finished.
+// The pass chain is enqueued in chunks and the finished-pixel counter is polled once per chunk (one chunk ahead of the one being waited
+// for), so this render returns when the frame is complete: the call is synchronous on `stream`.
+static int render_wfg(const rl_scene *scene, RtiowParams &P, uint32_t nrows, hipStream_t stream, bool trans) {
+  rl_scene *ms = const_cast<rl_scene *>(scene);  // work buffers only; the scene program is immutable
+  const size_t npix = (size_t)nrows * P.cam.image_width, nslots = P.n_slots;
+  if (ms->wfg_pix_cap < npix || ms->wfg_slot_cap < nslots) {
+    hipFree(ms->d_wfg_pix), hipFree(ms->d_wfg_ray), hipFree(ms->d_wfg_q0), hipFree(ms->d_wfg_q1), hipFree(ms->d_wfg_qs);
+    ms->d_wfg_pix = nullptr, ms->d_wfg_ray = nullptr, ms->d_wfg_q0 = ms->d_wfg_q1 = ms->d_wfg_qs = nullptr, ms->wfg_pix_cap = ms->wfg_slot_cap = 0;
+    HIP_TRY(hipMalloc((void **)&ms->d_wfg_pix, npix * sizeof(WfgPix)));
+    HIP_TRY(hipMalloc((void **)&ms->d_wfg_ray, npix * sizeof(WfgRay)));
+    HIP_TRY(hipMalloc((void **)&ms->d_wfg_q0, nslots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ms->d_wfg_q1, nslots * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ms->d_wfg_qs, nslots * sizeof(uint32_t)));
+    ms->wfg_pix_cap = npix, ms->wfg_slot_cap = nslots;
+  }
+  if (!ms->d_wfg_ctl) HIP_TRY(hipMalloc((void **)&ms->d_wfg_ctl, WFG_CTL_WORDS * sizeof(uint32_t)));
+  if (!ms->h_wfg) HIP_TRY(hipHostMalloc((void **)&ms->h_wfg, 64, hipHostMallocDefault));
+  WfgParams Q{};
+  Q.pix = (WfgPix *)ms->d_wfg_pix, Q.ray = (WfgRay *)ms->d_wfg_ray, Q.queue[0] = ms->d_wfg_q0, Q.queue[1] = ms->d_wfg_q1, Q.slow_queue = ms->d_wfg_qs, Q.ctl = ms->d_wfg_ctl;
+  P.sample_begin = 0, P.sample_end = P.cam.samples_per_pixel, P.resume = 0, P.pos_state = nullptr, P.tile_order = nullptr, P.tile_cost = nullptr;
+  if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
+  hipLaunchKernelGGL(wfg_init, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, stream, P, Q);
+  HIP_TRY(hipGetLastError());
+  constexpr int LNT = 256;                         // wfg_logic: blocks of one wave per SIMD, 3 (2 with transcendental textures) per CU, rings in LDS
+  const size_t llds = (size_t)16 * LNT * sizeof(unsigned long long);
+  constexpr int TNT = 256, TSD = 20;               // wfg_trav: 20-entry stacks in LDS, register budget of `twpe` waves per SIMD
+  const size_t tlds = (size_t)TSD * TNT * sizeof(uint32_t);
+  const int twpe = (g_sw.tune_set && (g_sw.tune[2] == 4 || g_sw.tune[2] == 5 || g_sw.tune[2] == 8)) ? (int)g_sw.tune[2] : 6;  // A/B: RL_TUNE third field
+  const uint32_t lblocks = (uint32_t)g_cus * (trans ? 2u : 3u), tblocks = (uint32_t)g_cus * (uint32_t)twpe;
+  const uint32_t sblocks = (uint32_t)g_cus;  // the slow queue holds a fraction of a percent of a pass's rays
+  const void *tk = twpe == 4 ? (const void *)wfg_trav<TNT, TSD, 4> : twpe == 5 ? (const void *)wfg_trav<TNT, TSD, 5> : twpe == 8 ? (const void *)wfg_trav<TNT, TSD, 8> : (const void *)wfg_trav<TNT, TSD, 6>;
+  if (ensure_lds_attr(trans ? (const void *)wfg_logic<LNT, true, false> : (const void *)wfg_logic<LNT, false, false>, llds) != 0 ||
+      ensure_lds_attr(trans ? (const void *)wfg_logic<LNT, true, true> : (const void *)wfg_logic<LNT, false, true>, llds) != 0 || ensure_lds_attr(tk, tlds) != 0)
+    return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  const int CHUNK = 16;
+  volatile uint32_t *h_done = (volatile uint32_t *)ms->h_wfg;
+  uint32_t pass = 0;
+  for (long chunk = 0; chunk < (1l << 36); chunk++) {
+    for (int k = 0; k < CHUNK; k++, pass++) {
+      Q.in = pass & 1u;
+      if (trans) {
+        hipLaunchKernelGGL((wfg_logic<LNT, true, false>), dim3(lblocks), dim3(LNT), llds, stream, P, Q);
+        hipLaunchKernelGGL((wfg_logic<LNT, true, true>), dim3(sblocks), dim3(LNT), llds, stream, P, Q);
+      } else {
+        hipLaunchKernelGGL((wfg_logic<LNT, false, false>), dim3(lblocks), dim3(LNT), llds, stream, P, Q);
+        hipLaunchKernelGGL((wfg_logic<LNT, false, true>), dim3(sblocks), dim3(LNT), llds, stream, P, Q);
+      }
+      if (twpe == 4) hipLaunchKernelGGL((wfg_trav<TNT, TSD, 4>), dim3(tblocks), dim3(TNT), tlds, stream, P, Q);
+      else if (twpe == 5) hipLaunchKernelGGL((wfg_trav<TNT, TSD, 5>), dim3(tblocks), dim3(TNT), tlds, stream, P, Q);
+      else if (twpe == 8) hipLaunchKernelGGL((wfg_trav<TNT, TSD, 8>), dim3(tblocks), dim3(TNT), tlds, stream, P, Q);
+      else hipLaunchKernelGGL((wfg_trav<TNT, TSD, 6>), dim3(tblocks), dim3(TNT), tlds, stream, P, Q);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync((void *)h_done, ms->d_wfg_ctl + WFG_DONE, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (*h_done >= npix) break;
+  }
+  return RL_OK;
+}
+
+#endif
+
 namespace rl {
 int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, void *d_out,
                         hipStream_t stream, bool want_stats) {
@@ -690,13 +759,20 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // wave-scheduled one as a scope of the threaded program, the nested-loop one by recursion: RL_RTIOW_KERNEL=general); no fast traversal
   if (rt.has_media && variant != 2) variant = 4;
 #ifndef RL_EXPERIMENTAL
-  if (variant == 1 || variant == 3 || variant == 5 || variant == 6 || variant == 7 || variant == 256 || variant == 512 || variant == 768)
+  if (variant == 1 || variant == 3 || variant == 5 || variant == 6 || variant == 7 || variant == 256 || variant == 512 || variant == 768 || variant == 1035)
     return set_err(RL_E_UNSUPPORTED, "this kernel variant is A/B material and lives in librl_render_exp.so only (make -C rendering-learning_amd/csrc exp)");
 #endif
   // 1031 = the FAST traversal for general scenes (rl_rtiow_fastgen.h): counter-free renders only, like 1029
   const bool fits_fastg = general && H.fg.ok && (!want_stats) && g_sw.fast_traversal;
   if (variant == 2) variant = 2;               // the nested-loop all-primitives kernel (A/B reference)
-  else if ((variant == 0 || variant == 1031) && fits_fastg) variant = 1031;
+  else if ((variant == 0 || variant == 1031 || variant == 1035) && fits_fastg) {
+    // 1035 = the same traversal in WAVEFRONT form (experimental/rl_rtiow_wfg.h): measured, slower, experimental library only
+    bool wf = false;
+#ifdef RL_EXPERIMENTAL
+    wf = (variant == 1035 || (variant == 0 && g_sw.wavefront == 1)) && (uint64_t)nrows * W < 0xFFFF0000ull;
+#endif
+    variant = wf ? 1035 : 1031;
+  }
   else if (general || variant == 4 || variant == 1031) variant = 4;  // wave-scheduled all-primitives kernel (scene read from HBM/L2)
   const size_t compact_bytes = ((size_t)n_cops * sizeof(CompactOp) + (((size_t)P.n_spheres + 31) / 32 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
   bool fits_compact = n_cops != 0 && (size_t)16 * 1024 * sizeof(unsigned long long) + compact_bytes <= g_lds_max;
@@ -778,10 +854,14 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       else
 #endif
         rc = want_stats ? launch(rtiow_general_kernel<NT, true, 512>, NT, rb, false) : launch(rtiow_general_kernel<NT, false, 512>, NT, rb, false);
+#ifdef RL_EXPERIMENTAL
+    } else if (variant == 1035) {
+      rc = render_wfg(scene, P, nrows, stream, rt.has_noise || rt.has_sphere_uv);
+#endif
     } else if (variant == 1031) {  // rings + the traversal stacks in LDS
       // four steps per scheduling round (a step is an Infinity Cache / L2 round trip here, not an LDS one: lanes that fall out of TRAV
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
-      if (!g_sw.tune_set) P.tune[0] = 4;
+      if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
       if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
         constexpr int NT = 512, SD = 40;
@@ -892,7 +972,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   // with their exact sums and ChaCha word positions: results are bit-identical to a single launch.
   const bool lpt_enabled = g_sw.lpt;
   const uint32_t lpt_first = 8;
-  bool lpt = lpt_enabled && (variant >= 256 || variant == 4 || variant == 1031 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
+  bool lpt = lpt_enabled && variant != 1035 && (variant >= 256 || variant == 4 || variant == 1031 || variant == 5 || variant == 6 || variant == 7) && cam->samples_per_pixel >= 64;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   int rc = RL_OK;
   if (variant == 3) {

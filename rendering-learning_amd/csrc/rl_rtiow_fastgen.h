@@ -87,6 +87,13 @@ __device__ __forceinline__ uint32_t general_slow_trace(const RtiowParams &P, con
   return flags;
 }
 
+// A fast walk that has taken this many steps (nodes + primitive tests) is given up: the ray is re-traced by the reference's own fold, which
+// prunes by ITS boxes (cfg 5: ~140 tests).  The rays that get here are far-origin rays (`unsafe`: every box widened by `grow`, no pruning by
+// the closest hit) whose widened boxes overlap half the scene — a handful per frame walk 1e5 ... 1e6 steps, 30 ... 460 ms EACH in a
+// traversal-only launch, and the megakernel's last lanes were those too: cfg 5 at 64 spp 2.54 -> 1.87 s.  Any budget is correct (the fold
+// is the reference); measured at 64 spp: 64 steps 3.56 s (16.7 M rays re-traced), 128: 2.20 s (5.1 M), 256: 1.89 s, 512: 1.87 s, 2048: 1.88 s
+// (4.15 M: the rays that are re-traced for other reasons).
+static const uint32_t FASTG_STEP_BUDGET = 512;
 #ifdef RL_FASTG_VERIFY  // debug build (tools/verify_fastg.py): every ray is ALSO traced in the reference's order; mismatches are logged
 __device__ unsigned int g_vcount;
 __device__ double g_vlog[64][12];
@@ -184,7 +191,8 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
   D3 thr = d3(1.0, 1.0, 1.0);
   RayAux32 ra32 = ray_aux32_direct(wo, wd);
   double time = 0.0, closest = INF;
-  uint32_t pc = 0, best = NONE, depth = 0, sp = 0;
+  uint32_t pc = 0, best = NONE, depth = 0, sp = 0, steps = 0;
+  const uint32_t step_budget = P.tune[3];
   bool amb = false;
   // rays that start farther than r_safe from the scene's centre (e.g. inside a huge ground sphere): the boxes' padding was sized for
   // origins inside r_safe, so such a ray widens every box interval by `grow` and does NOT prune by the closest hit — every sphere its
@@ -197,6 +205,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
 #endif
 
   auto go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), an item (LEAF), or nothing left (SHADE)
+    if (++steps > step_budget) amb = true, e = NONE;
     if (e == NONE) {
 #ifdef RL_FASTG_VERIFY
       if (false) {
@@ -218,7 +227,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
     return s_stack[(size_t)sp * NT + tid];
   };
   auto start_ray = [&]() {
-    closest = INF, best = NONE, sp = 0;
+    closest = INF, best = NONE, sp = 0, steps = 0;
     ra32 = ray_aux32_direct(wo, wd);
     float fx = (float)wo.x - P.fg_center[0], fy = (float)wo.y - P.fg_center[1], fz = (float)wo.z - P.fg_center[2];
     float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
@@ -274,6 +283,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
             else amb = true;  // more pending children than the stack holds: the reference's order decides
           };
           const Float4 *nd = (const Float4 *)(nodes + pc);
+          // Measured and dropped (round 3, RL_TUNE experiment bits): the node's first 16 bytes alone, then an s_waitcnt, then the other six
+          // loads (so that they find the line in L1 instead of pending): cfg 5 -2.5 %, cfg 4 -1 %; the same 112 bytes as fourteen 8-byte
+          // loads (twice the L1 accesses): cfg 5 -9.5 %, cfg 4 -3.5 % — the L1 access rate is a second-order cost, not the bound.
           const Float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
           const uint4 ch = *(const uint4 *)(nd + 6);
           float k0, k1, k2, k3;

@@ -103,6 +103,11 @@ struct rl_scene {
   size_t shard_bytes = 0;
   hipEvent_t ev_gather_read = nullptr;  // replica 0: recorded behind the de-interleave kernel that reads the gather slots
   bool ev_gather_read_valid = false;
+  // wavefront form (rl_rtiow_wfg.h): per-pixel records, ray records, the two queues, control words, the polled word in pinned memory
+  void *d_wfg_pix = nullptr, *d_wfg_ray = nullptr;
+  uint32_t *d_wfg_q0 = nullptr, *d_wfg_q1 = nullptr, *d_wfg_qs = nullptr, *d_wfg_ctl = nullptr;
+  size_t wfg_pix_cap = 0, wfg_slot_cap = 0;
+  void *h_wfg = nullptr;
   uint32_t *d_pix_rays = nullptr;  // debug (tools/): per-pixel ray counts of the last counting render
   void *exp = nullptr;             // experimental kernels' work buffers (rl_render.hip, RL_EXPERIMENTAL builds only)
 };

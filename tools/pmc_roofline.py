@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 counter passes over ONE config's timed kernel -> gpurun_out/<out>/roofline_<cfg>.json (copied to profiles/ by hand).
 
-usage (on the GPU box, through gpurun):  python3 tools/pmc_roofline.py <out> <cfg2|cfg3_aa1|cfg3_aa8|cfg4|cfg5> [spp] [sq|mem|all]
+usage (on the GPU box, through gpurun):  python3 tools/pmc_roofline.py <out> <cfg2|cfg3_aa1|cfg3_aa8|cfg4|cfg5> [spp] [sq|mem|ic|all]
 
 Every pass is its own `rocprofv3 --pmc <set> -- python3 tools/cfg_workload.py <cfg> <spp>` (counters only: never combined with a trace), at
 most 8 SQ / 4 TCC / 4 TCP counters per pass (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots").
@@ -39,7 +39,9 @@ MEM = ["FETCH_SIZE GRBM_GUI_ACTIVE",
        "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_READ_sum",
        "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_PENDING_STALL_CYCLES_sum",
        "TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum"]
-sets = (SQ if which in ("sq", "all") else []) + (MEM if which in ("mem", "all") else [])
+IC = ["SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY",
+      "SQC_TC_INST_REQ SQC_ICACHE_BUSY_CYCLES SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_IFETCH_LEVEL SQ_INSTS_SMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"]
+sets = (SQ if which in ("sq", "all") else []) + (MEM if which in ("mem", "all") else []) + (IC if which in ("ic", "all") else [])
 env = dict(os.environ, TMPDIR="/tmp")
 c = collections.defaultdict(float)
 launches = {}
@@ -142,6 +144,10 @@ if have("TCP_UTCL1_REQUEST_sum", "TCP_UTCL1_TRANSLATION_MISS_sum"):
     res["utcl1_miss_rate"] = c["TCP_UTCL1_TRANSLATION_MISS_sum"] / max(1.0, c["TCP_UTCL1_REQUEST_sum"])
 if have("TCP_TCP_LATENCY_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"):
     res["tcp_latency_cycles_per_access"] = c["TCP_TCP_LATENCY_sum"] / max(1.0, c["TCP_TOTAL_CACHE_ACCESSES_sum"])
+if have("SQC_ICACHE_REQ", "SQC_ICACHE_MISSES"):
+    res["icache_miss_rate"] = c["SQC_ICACHE_MISSES"] / max(1.0, c["SQC_ICACHE_REQ"])
+    res["icache_requests_per_ray"] = c["SQC_ICACHE_REQ"] / rays
+    res["icache_misses_per_ray"] = c["SQC_ICACHE_MISSES"] / rays
 res["source"] = f"tools/pmc_roofline.py {out_tag} {cfg} {spp} {which}: rocprofv3 --pmc passes over tools/cfg_workload.py, summed over {res['launches_summed']} launches of the timed kernel"
 json.dump(res, open(os.path.join(OUT, f"roofline_{cfg}.json"), "w"), indent=1)
 print(json.dumps(res), flush=True)
