@@ -331,6 +331,14 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
+    # the collective layer describes itself: which backend, how many ranks it really spans (an all-reduce of ones)
+    comm = None
+    if world_size > 1:
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        comm = {"backend": dist.get_backend() + (" (REHEARSAL on one GPU through host memory: NOT RCCL)" if rehearsal else " (= RCCL on ROCm)"),
+                "world_size": dist.get_world_size(), "allreduce_ones": int(ones.item())}
+
     rl = importlib.import_module("rendering-learning_amd")
     sharding = importlib.import_module("rendering-learning_amd.sharding")
     G = args.gpus if args.inprocess else world_size
@@ -387,6 +395,19 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step()
     finish()
+    if world_size > 1:  # the exchange step alone (untimed run): rows already rendered, one gather to rank 0
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        exchange()
+        torch.cuda.synchronize(dev)
+        comm["gather_ms"] = (time.perf_counter() - g0) * 1e3
+        comm["gather_bytes_per_peer"] = int(shard.numel() * 8)
+    if args.inprocess:
+        L = rl.api.render_lib()
+        comm = {"mode": "one process, rl_init_multi", "devices": int(L.rl_device_count()), "library_uses_rccl": bool(L.rl_debug_multi_uses_rccl()),
+                "librccl_loadable": bool(L.rl_debug_rccl_loadable()),
+                "exchange": "ncclSend / ncclRecv in one group (rl_multi.hip)" if L.rl_debug_multi_uses_rccl() else "hipMemcpyPeerAsync (peer-copy fallback or emulated contexts)"}
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -425,6 +446,10 @@ def main():
     else:
         kernel_ms_max = kernel_ms
     rays, nodes, spheres, timed_rays = float(tot[0]), float(tot[1]), float(tot[2]), float(tot[5])
+    if world_size > 1:  # every rank's own kernel time (HIP events on its launch stream)
+        per_rank = [torch.zeros(1, dtype=torch.float64, device="cpu" if rehearsal else dev) for _ in range(world_size)]
+        dist.all_gather(per_rank, torch.tensor([kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev))
+        comm["per_rank_kernel_ms"] = [float(t.item()) for t in per_rank]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -451,9 +476,14 @@ def main():
                          "fp64_flop_per_ray": vp.get("fp64_flop_per_ray"),
                          "fp64_tflops": (vp["fp64_flop_per_ray"] * rank_rays / k_s / 1e12) if vp.get("fp64_flop_per_ray") else None,
                          "fp64_peak_tflops_unfused": 39.3,
-                         "traffic": vp.get("hbm_bytes_per_launch"),
+                         "traffic": (vp["hbm_bytes_per_ray"] * rank_rays / launches) if vp.get("hbm_bytes_per_ray") is not None else vp.get("hbm_bytes_per_launch"),
+                         "hbm_gbs": (vp["hbm_bytes_per_ray"] * rank_rays / k_s / 1e9) if vp.get("hbm_bytes_per_ray") is not None else None,
+                         "hbm_frac_of_8TBs": (vp["hbm_bytes_per_ray"] * rank_rays / k_s / 8e12) if vp.get("hbm_bytes_per_ray") is not None else None,
+                         "l2_hit_rate": vp.get("l2_hit_rate"), "pmc_spp": vp.get("pmc_spp"),
                          "per_ray_figures_from": vp.get("source"),
-                         "note": "per-ray instruction counts are rocprofv3 SQ counters of this kernel on this workload (profiles/, not collected in this run); "
+                         "note": ("per-ray instruction counts are rocprofv3 SQ counters of this kernel on this workload" +
+                                  ("" if vp.get("pmc_spp") == args.spp else f" at {vp.get('pmc_spp')} spp (this run: {args.spp}: the 8-sample probe launch has another share of the frame)") +
+                                  " (profiles/, not collected in this run); ") +
                                  "rays and kernel time are this run's. frac = valu_issue_frac x lanes_active_frac at the nominal 2.4 GHz; the scene is LDS / L2-resident, "
                                  "HBM traffic is the framebuffer"})
         else:
@@ -476,6 +506,8 @@ def main():
                        "rays_per_step": rays, "aabb_tests_per_ray": nodes / rays, "sphere_tests_per_ray": spheres / rays},
             "roofline": roof,
         }
+        if comm is not None:
+            out["rccl"] = comm
         if args.emulate_shard > 1:
             out["config"]["emulated_shard_of"] = args.emulate_shard
         if rehearsal or (args.inprocess and os.environ.get("RL_BENCH_EMULATE_DEVICES")):

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rl_scene.h"
@@ -47,6 +48,12 @@ struct Rccl {
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::vector<ncclComm_t> comms;  // one per device context
 } g_rccl;
+// the pointer types above are the installed header's own: a signature drift in <rccl/rccl.h> fails the build, not the first multi-GPU run
+static_assert(std::is_same<decltype(Rccl::CommInitAll), decltype(&ncclCommInitAll)>::value && std::is_same<decltype(Rccl::CommDestroy), decltype(&ncclCommDestroy)>::value &&
+                  std::is_same<decltype(Rccl::GroupStart), decltype(&ncclGroupStart)>::value && std::is_same<decltype(Rccl::GroupEnd), decltype(&ncclGroupEnd)>::value &&
+                  std::is_same<decltype(Rccl::Send), decltype(&ncclSend)>::value && std::is_same<decltype(Rccl::Recv), decltype(&ncclRecv)>::value &&
+                  std::is_same<decltype(Rccl::GetErrorString), decltype(&ncclGetErrorString)>::value,
+              "rl_multi.hip's RCCL entry points no longer match <rccl/rccl.h>");
 bool g_emulated = false;  // every context on ONE physical GPU (tests on a one-GPU box): peer-copy exchange, no communicators
 
 bool load_rccl() {
@@ -271,6 +278,9 @@ int rl_debug_init_multi_emulated(int G) {
   if (rc != RL_OK) return rc;
   return init_contexts(std::vector<int>((size_t)G, context(0).device), true);
 }
+
+// Not part of the ABI (CPU-tier test, bench.py): 1 when librccl can be loaded and every entry point the gather uses resolves — no device needed.
+int rl_debug_rccl_loadable(void) { return load_rccl() ? 1 : 0; }
 
 // Not part of the ABI: 1 when the exchange goes through RCCL communicators, 0 for peer copies.
 int rl_debug_multi_uses_rccl(void) { return !g_emulated && (int)g_rccl.comms.size() == n_contexts() && n_contexts() > 1; }

@@ -193,6 +193,12 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const floa
           c_flag += fast_slow_trace(ops, spheres, o, d, time, closest, hit_prim);
           c_slow++;
         }
+#ifdef RL_FASTG_VERIFY
+        else if (lane == 0) {  // the cooperative answer against the reference's fold
+          fast_verify_ray(ops, spheres, o, d, time, closest, hit_prim, 3.0);
+          atomicAdd(&g_vstats[3], 1ull);
+        }
+#endif
         if (hit_prim == NONE) {
           color = color + thr * background;
           break;

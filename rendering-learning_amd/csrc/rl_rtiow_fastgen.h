@@ -95,9 +95,7 @@ __device__ __forceinline__ uint32_t general_slow_trace(const RtiowParams &P, con
 // (4.15 M: the rays that are re-traced for other reasons).
 static const uint32_t FASTG_STEP_BUDGET = 512;
 #ifdef RL_FASTG_VERIFY  // debug build (tools/verify_fastg.py): every ray is ALSO traced in the reference's order; mismatches are logged
-__device__ unsigned int g_vcount;
-__device__ double g_vlog[64][12];
-__device__ unsigned long long g_vstats[4];  // TRAV steps, LEAF visits, far-origin rays
+// (g_vcount / g_vlog / g_vstats: rl_rtiow_wave.h — the sphere kernels log into them too)
 #endif
 // Sphere::hit / Plane::hit_ab for the ROOT only, acceptance window widened by the tie band (see fast_sphere_hit in rl_rtiow_wave.h)
 __device__ __forceinline__ void fastg_planar_hit(const DevPlanar &pl, D3 o, D3 d, float oimax, uint32_t item, double &closest, uint32_t &best, bool &amb) {

@@ -321,6 +321,25 @@ __device__ __forceinline__ uint32_t fast_slow_trace(const DevOp *ops, const DevS
   return flags;
 }
 
+#ifdef RL_FASTG_VERIFY  // debug build (make verify, tools/verify_fastg.py): every ray of the fast kernels is ALSO traced in the reference's order
+__device__ unsigned int g_vcount;                                 // rays whose two answers differ
+__device__ double g_vlog[64][12];                                  // the first 64 of them
+__device__ unsigned long long g_vstats[4];                         // general kernel: TRAV steps, LEAF visits, far-origin rays; [3] rays verified by the sphere kernels
+__device__ __forceinline__ void fast_verify_ray(const DevOp *ops, const DevSphere *spheres, D3 o, D3 d, double time, double closest, uint32_t hit_prim, double who) {
+  double c2;
+  uint32_t h2;
+  fast_slow_trace(ops, spheres, o, d, time, c2, h2);
+  const bool same = (hit_prim == NONE) == (h2 == NONE) && (h2 == NONE || ((h2 & SPH_INDEX) == (hit_prim & SPH_INDEX) && c2 == closest));
+  if (!same) {
+    unsigned k = atomicAdd(&g_vcount, 1u);
+    if (k < 64) {
+      double *L = g_vlog[k];
+      L[0] = o.x, L[1] = o.y, L[2] = o.z, L[3] = d.x, L[4] = d.y, L[5] = d.z, L[6] = time, L[7] = hit_prim == NONE ? -1.0 : closest;
+      L[8] = (double)(hit_prim & SPH_INDEX), L[9] = h2 == NONE ? -1.0 : c2, L[10] = (double)(h2 & SPH_INDEX), L[11] = who;
+    }
+  }
+}
+#endif
 // rl_rtiow_coop.h (included after this header): what a wave of the STEAL instantiation runs once all its lanes have run out of pixels
 template <int NT>
 __device__ __forceinline__ void rtiow_steal_loop(const RtiowParams &P, unsigned long long *s_rng);
@@ -446,6 +465,12 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   };
   auto fast_go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), a sphere (LEAF), or nothing left
     if (e == FAST_NONE) {
+#ifdef RL_FASTG_VERIFY
+      if (LDS_SCENE == 4 && !amb) {  // a walk that trusts its own answer: the reference's fold must give the same one
+        fast_verify_ray(P.ops, spheres, o, d, time, closest, hit_prim, 2.0);
+        atomicAdd(&g_vstats[3], 1ull);
+      }
+#endif
       if (amb) pc = FAST_SLOW, state = ST_LEAF;
       else if (hit_prim == NONE) {  // a miss needs no SHADE visit: background (camera.rs:257), sample done (+10 %)
         sum = sum + thr * ld3(P.cam.background);

@@ -64,3 +64,11 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "rl_oracle" not in txt and "rlo_" not in txt and "oracle/" not in txt, os.path.join(dp, f)
+
+
+def test_rccl_entry_points_resolve_without_a_device(rl):
+    """The multi-GPU exchange (csrc/rl_multi.hip: ncclCommInitAll, ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, ncclCommDestroy,
+    ncclGetErrorString) binds librccl at run time.  Here, without a GPU: the library loads and every entry point resolves; that the call
+    sequence matches the installed <rccl/rccl.h> is a static_assert in rl_multi.hip (a drifted signature fails the build).  The send / recv
+    pair itself needs >= 2 physical GPUs and has not executed on hardware yet (README.md / INTEGRATION.md say so)."""
+    assert rl.api.render_lib().rl_debug_rccl_loadable() == 1

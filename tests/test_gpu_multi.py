@@ -58,6 +58,21 @@ for G in (2, 3, 8):
     cam.render_multi_device(world, buf.data_ptr())
     st = api.render_status(world)
     assert np.array_equal(buf.cpu().numpy(), single) and st["rays"] == gs["rays"], G
+    # two asynchronous frames back to back, no rl_render_status in between: the second frame's shards must not land in the gather slots
+    # before the first frame's de-interleave has read them (ADVICE r02: the peer-copy gather used to race here)
+    quick = rl.Camera(rl.CameraParams(**{**p.__dict__, "samples_per_pixel": 3, "seed": 9}))
+    quick_ref = None
+    for attempt in range(3):
+        a = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+        b = torch.full_like(a, float("nan"))
+        torch.cuda.synchronize()
+        cam.render_multi_device(world, a.data_ptr())
+        quick.render_multi_device(world, b.data_ptr())
+        api.render_status(world)
+        if quick_ref is None:
+            quick_ref = quick.render_multi(world).data
+        assert np.array_equal(a.cpu().numpy(), single), (G, attempt)
+        assert np.array_equal(b.cpu().numpy(), quick_ref), (G, attempt)
     rw = rl.RtcWorld.test_obj_scene(golden("teapot-low.obj"), 90, 61)
     rms = {}
     assert np.array_equal(rw.render_multi(2, stats=rms), rsingle), G

@@ -1,5 +1,9 @@
-"""Debug (make -C rendering-learning_amd/csrc verify; RL_RENDER_LIB=.../librl_render_verify.so): renders the cfg-5 scene with the fast
-general kernel tracing EVERY ray in the reference's order as well, and prints the rays whose two answers differ."""
+"""Debug (make -C rendering-learning_amd/csrc verify; RL_RENDER_LIB=.../librl_render_verify.so): renders a scene with the fast kernels
+tracing EVERY ray in the reference's order as well, and prints the rays whose two answers differ.
+usage: verify_fastg.py <spp> [cfg5 | cow | spheres [width] | coop [width]]
+  cfg5 / cow   rtiow_fast_general_kernel (BASELINE configs[4] / [3] at 3840 x 2160)
+  spheres      rtiow_wave_kernel<1024, 4, false> (BASELINE configs[1] scene; width 1920 = the headline frame)
+  coop         the cooperative one-wave-per-pixel kernel on the same scene (small frames; forced here)"""
 import ctypes as C, gzip, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -8,8 +12,12 @@ from PIL import Image
 rl.init(0)
 G = os.path.join(ROOT, "tests", "golden")
 tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB")); obj = gzip.open(os.path.join(G, "spot_triangulated.obj.gz"), "rb").read()
-if len(sys.argv) > 2 and sys.argv[2] == "cow":
+mode = sys.argv[2] if len(sys.argv) > 2 else "cfg5"
+if mode == "cow":
     w = rl.World.cow_scene(obj, tex); p = w.params; p.aspect_ratio, p.image_width = 16.0 / 9.0, 3840
+elif mode in ("spheres", "coop"):
+    w = rl.World.bouncing_spheres(1); p = w.params; p.image_width, p.max_depth = int(sys.argv[3]) if len(sys.argv) > 3 else 1920, 50
+    rl.api.set_rtiow_variant(1033 if mode == "coop" else 1029)
 else:
     w = rl.World.stress_scene(1000, 2, obj, tex); p = w.params
 p.samples_per_pixel = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -22,8 +30,9 @@ cnt = C.c_uint32(); log = (C.c_double * 768)()
 L.rl_debug_fastg_verify(C.byref(cnt), log)
 print("rays", st["rays"], "mismatching rays", cnt.value)
 c4 = (C.c_uint64 * 4)(); L.rl_debug_fastg_counts(c4)
-print("per ray: TRAV steps %.2f  LEAF visits %.2f  far-origin rays %.4f" % (c4[0] / st["rays"], c4[1] / st["rays"], c4[2] / st["rays"]))
+print("per ray: TRAV steps %.2f  LEAF visits %.2f  far-origin rays %.4f;  rays verified by the sphere kernels: %d (the others were re-traced anyway: %d)" %
+      (c4[0] / st["rays"], c4[1] / st["rays"], c4[2] / st["rays"], c4[3], st["slow_traces"]))
 a = np.array(log).reshape(64, 12)
 np.set_printoptions(precision=17, linewidth=250)
 for r in a[:min(cnt.value, 8)]:
-    print("o", r[0:3], "d", r[3:6], "time", r[6], "fast t", r[7], "fast op", r[8], "ref t", r[9], "ref op", r[10], "unsafe", r[11])
+    print("o", r[0:3], "d", r[3:6], "time", r[6], "fast t", r[7], "fast op", r[8], "ref t", r[9], "ref op", r[10], "unsafe / kernel (2 = sphere wave kernel, 3 = cooperative)", r[11])
