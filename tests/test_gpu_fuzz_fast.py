@@ -28,9 +28,12 @@ def _world(api, rng, kind):
     scale = 10.0 ** rng.uniform(-6, 6) if kind == "scaled" else 1.0
     if kind == "ratios":  # radius ratios up to 1e6: pebbles on and around boulders
         n = int(rng.integers(3, 40))
-        big = 10.0 ** rng.uniform(1, 3)
+        # half of the worlds stay below the ratio at which the from_normalized assert (vec3.rs:219) becomes reachable and the scene
+        # therefore gets NO fast structure (GuardFrame::normals_safe: extent / radius <~ 2.6e4); the other half go up to 1e6 (fallback path)
+        tame = rng.random() < 0.5
+        big = 10.0 ** (rng.uniform(1, 1.5) if tame else rng.uniform(1, 3))
         c = rng.uniform(-2, 2, (n, 3))
-        r = 10.0 ** rng.uniform(-3, 0, n) * 0.5
+        r = 10.0 ** (rng.uniform(-2, 0, n) if tame else rng.uniform(-3, 0, n)) * 0.5
         c[0], r[0] = (0.0, -big - 0.5, 0.0), big  # the ground: big / min(r) up to 1e6
         k = n // 2
         d = rng.normal(size=(k, 3))
@@ -111,6 +114,6 @@ def test_fast_and_cooperative_kernels_equal_the_counting_kernel_on_adversarial_w
             assert st["rays"] == gs["rays"] and st["flagged"] == gs["flagged"], (kind, case, v)
         slow += frames[1029][1]["slow_traces"]
         rays += gs["rays"]
-    assert fast_structures >= 12, fast_structures  # the fuzz must exercise the fast structure, not only its fallbacks
+    assert fast_structures >= (6 if kind == "ratios" else 12), fast_structures  # the fuzz must exercise the fast structure, not only its fallbacks
     if kind == "nested":
         assert slow > 0  # near-coincident shells: the tie band must fire
