@@ -17,9 +17,14 @@
  * Conventions: plain pointers and sizes only; 0 on success, negative RL_E_* otherwise; the
  * library never unwinds or aborts across the boundary (every reference panic site becomes an
  * error code or a flagged-pixel count); scene_create deep-copies, so the caller may free its
- * arrays as soon as it returns; an rl_scene's program is immutable but it owns per-render scratch
- * (counters, the cost-sorted tile order), so renders of ONE scene must not overlap — use one scene
- * handle per concurrent render; the caller owns all host pointers.
+ * arrays as soon as it returns; the caller owns all host pointers.
+ * Concurrency: as Camera::render takes `&self` and a `Sync` world (camera.rs:122), every render entry point may be
+ * called on ONE rl_scene from several host threads and on several HIP streams at once.  The scene's program is
+ * immutable; it owns one set of work buffers (counters, the cost-sorted tile order), so the library serialises the
+ * host side per scene and makes a render wait on the device for the scene's previous one when their streams differ:
+ * concurrent callers get the frames a lone caller gets, rendered one after the other (each fills the GPU).  Use
+ * several scene handles for renders that should share the GPU.  rl_init / rl_init_multi / rl_shutdown / scene
+ * creation and destruction are NOT to be raced against renders.
  * Everything is IEEE binary64 unless stated.  There is NO CPU fallback: without a GPU / without
  * the HIP code object every compute entry point fails with RL_E_NO_DEVICE.
  */
@@ -32,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 5
+#define RL_ABI_VERSION 6
 
 /* ------------------------------------------------------------------ errors */
 #define RL_OK 0
@@ -252,9 +257,10 @@ int rl_rtiow_render_device(const rl_scene *, const rl_rtiow_camera *, uint64_t f
                            uint32_t row_first, uint32_t row_step, void *d_out_rgb_sum,
                            void *hip_stream, rl_stats *opt_stats);
 
-/* Completion + status of the last ASYNCHRONOUS render of this scene (rl_*_render_device / rl_*_render_multi_device with
- * opt_stats == NULL): waits for it, fills opt_stats->rays and ->flagged (the other counters need a counting render) and returns
- * RL_E_DEGENERATE if a reference panic site (camera.rs:86, material.rs:151, vec3.rs:220, ...) was reached, else RL_OK. */
+/* Completion + status of the ASYNCHRONOUS renders of this scene since the last call (rl_*_render_device / rl_*_render_multi_device
+ * with opt_stats == NULL): waits for all of them, fills opt_stats->rays with the ray count of the most recently enqueued one and
+ * ->flagged with the panic sites reached by any of them (the other counters need a counting render) and returns RL_E_DEGENERATE
+ * if a reference panic site (camera.rs:86, material.rs:151, vec3.rs:220, ...) was reached, else RL_OK. */
 int rl_render_status(const rl_scene *, rl_stats *opt_stats);
 
 /* Camera::render on every GPU of rl_init_multi: image row r is rendered by GPU r mod G with the single-GPU

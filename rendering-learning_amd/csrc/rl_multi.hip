@@ -105,6 +105,7 @@ __global__ void deinterleave_rows(const double *gathered, double *out, uint32_t 
 template <class F>
 int render_multi(const rl_scene *scene, uint32_t W, uint32_t H, void *d_out0, rl_stats *st, F render_shard) {
   const int G = n_contexts();
+  std::lock_guard<std::mutex> lk(scene->mu);  // one multi-GPU frame of a scene at a time on the host side (rl_scene::mu)
   // a scene created under another rl_init / rl_init_multi holds buffers on device contexts that are gone (or never were):
   // refuse it rather than render on one GPU silently or touch a device context 0 no longer points at
   if (G > 1 && (int)scene->replicas.size() != G) return set_err_public(RL_E_INVALID, "scene was created before rl_init_multi: recreate it so that every device holds a replica");
@@ -207,9 +208,11 @@ int post_status_multi(const rl_scene *scene, uint32_t H) {
     rl_scene *r = scene->replicas.empty() ? const_cast<rl_scene *>(scene) : scene->replicas[(size_t)g];
     int rc = use_context(g);
     if (rc != RL_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(r->h_status, r->d_scratch + 64, 64, hipMemcpyDeviceToHost, context(g).stream));
-    HIP_TRY(hipEventRecord(r->ev_done, context(g).stream));
-    r->async_pending = true;
+    {
+      std::lock_guard<std::mutex> lk(r->mu);
+      rc = post_status(r, context(g).stream);
+    }
+    if (rc != RL_OK) return rc;
     if (scene->replicas.empty()) break;
   }
   return use_context(0);

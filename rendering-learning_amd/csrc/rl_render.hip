@@ -268,9 +268,11 @@ static void destroy_one(rl_scene *s) {
   }
 #endif
   if (s->h_status) hipHostFree(s->h_status);
+  for (hipEvent_t e : s->ev_status)
+    if (e) hipEventDestroy(e);
+  if (s->ev_last) hipEventDestroy(s->ev_last);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
-  if (s->ev_done) hipEventDestroy(s->ev_done);
   if (s->ev_gather_read) hipEventDestroy(s->ev_gather_read);
   hipFree(s->d_wfg_pix), hipFree(s->d_wfg_ray), hipFree(s->d_wfg_q0), hipFree(s->d_wfg_q1), hipFree(s->d_wfg_qs), hipFree(s->d_wfg_ctl);
   if (s->h_wfg) hipHostFree(s->h_wfg);
@@ -289,9 +291,10 @@ static int scene_common(rl_scene *s) {
   HIP_TRY(hipMemset(s->d_scratch, 0, 512));
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
-  HIP_TRY(hipHostMalloc((void **)&s->h_status, 64, hipHostMallocDefault));
-  std::memset(s->h_status, 0, 64);
+  for (hipEvent_t &e : s->ev_status) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_last, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc((void **)&s->h_status, (size_t)rl_scene::N_STATUS * 64, hipHostMallocDefault));
+  std::memset(s->h_status, 0, (size_t)rl_scene::N_STATUS * 64);
   return RL_OK;
 }
 
@@ -543,14 +546,40 @@ int collect_stats(const rl_scene *scene, hipStream_t stream, rl_stats *st) {
 }
 }  // namespace rl
 
-// asynchronous renders: leave the stats words in pinned host memory behind an event (rl_render_status reads them)
-static int post_status(const rl_scene *scene, hipStream_t stream) {
+namespace rl {
+// one finished slot of the status ring -> the scene's folded figures (rays: of the most recently enqueued render)
+static void fold_status(rl_scene *ms, int slot) {
+  const unsigned long long *h = ms->h_status + (size_t)slot * 8;
+  ms->folded_flagged += h[6], ms->folded_slow += h[7];
+  if (ms->status_seq[slot] > ms->folded_seq) ms->folded_seq = ms->status_seq[slot], ms->folded_rays = h[0];
+  ms->status_pending[slot] = false;
+}
+// asynchronous renders: leave the stats words in pinned host memory behind an event (rl_render_status reads them).  Caller holds scene->mu.
+int post_status(const rl_scene *scene, hipStream_t stream) {
   rl_scene *ms = const_cast<rl_scene *>(scene);
-  HIP_TRY(hipMemcpyAsync(ms->h_status, scene->d_scratch + 64, 64, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(ms->ev_done, stream));
-  ms->async_pending = true;
+  const int slot = ms->status_next;
+  if (ms->status_pending[slot]) {  // the ring has come round: N_STATUS renders are in flight, wait for the oldest
+    HIP_TRY(hipEventSynchronize(ms->ev_status[slot]));
+    fold_status(ms, slot);
+  }
+  HIP_TRY(hipMemcpyAsync(ms->h_status + (size_t)slot * 8, scene->d_scratch + 64, 64, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(ms->ev_status[slot], stream));
+  ms->status_pending[slot] = true, ms->status_seq[slot] = ++ms->next_seq;
+  ms->status_next = (slot + 1) % rl_scene::N_STATUS;
   return RL_OK;
 }
+int order_after_previous(const rl_scene *scene, hipStream_t stream) {
+  if (scene->has_last && scene->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, scene->ev_last, 0));
+  return RL_OK;
+}
+int mark_render_end(const rl_scene *scene, hipStream_t stream) {
+  rl_scene *ms = const_cast<rl_scene *>(scene);
+  HIP_TRY(hipEventRecord(ms->ev_last, stream));
+  ms->last_stream = stream, ms->has_last = true;
+  return RL_OK;
+}
+}  // namespace rl
+using rl::post_status;
 
 #ifdef RL_EXPERIMENTAL
 // Wavefront (v3) driver: one PASS = begin_pass, TRAV, SHADE, GEN (rl_rtiow_wavefront.h); passes are enqueued in
@@ -733,6 +762,10 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.tune[0] = g_sw.tune[0], P.tune[1] = g_sw.tune[1], P.tune[2] = g_sw.tune[2], P.tune[3] = g_sw.tune[3];
   P.pix_rays = want_stats ? scene->d_pix_rays : nullptr;
 
+  {
+    int rco = order_after_previous(scene, stream);
+    if (rco != RL_OK) return rco;
+  }
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
   auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
@@ -1040,6 +1073,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     rc = launch_variant();
   }
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
+  if (rc == RL_OK) rc = mark_render_end(scene, stream);
   return rc;
 }
 }  // namespace rl
@@ -1056,6 +1090,7 @@ int rl_rtiow_render_device(const rl_scene *scene, const rl_rtiow_camera *cam, ui
     if (st) std::memset(st, 0, sizeof *st);
     return RL_OK;
   }
+  std::lock_guard<std::mutex> lk(scene->mu);  // concurrent renders of one scene: see rl_scene::mu
   int rc = rl::rtiow_render_launch(scene, cam, first_sample, row_first, row_step, d_out, stream, st != nullptr);
   if (rc != RL_OK) return rc;
   return st ? rl::collect_stats(scene, stream, st) : post_status(scene, stream);
@@ -1073,15 +1108,24 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
   size_t n = scene->replicas.empty() ? 1 : scene->replicas.size();
   for (size_t g = 0; g < n; g++) {
     rl_scene *r = const_cast<rl_scene *>(scene->replicas.empty() ? scene : scene->replicas[g]);
-    if (!r->async_pending) continue;
-    if (r->ctx < 0 || (size_t)r->ctx >= g_ctx.size() || g_ctx[(size_t)r->ctx].device != r->device)
-      return set_err(RL_E_INVALID, "scene belongs to a device context that no longer exists (created under another rl_init / rl_init_multi)");
-    int rc = rl::use_context(r->ctx);
-    if (rc != RL_OK) return rc;
-    HIP_TRY(hipEventSynchronize(r->ev_done));
-    r->async_pending = false;
-    acc.rays += r->h_status[0], acc.flagged += r->h_status[6];
-    g_last_slow_traces += r->h_status[7];
+    std::lock_guard<std::mutex> lk(r->mu);
+    bool any = false;
+    for (int k = 0; k < rl_scene::N_STATUS; k++) any |= r->status_pending[k];
+    if (any) {
+      if (r->ctx < 0 || (size_t)r->ctx >= g_ctx.size() || g_ctx[(size_t)r->ctx].device != r->device)
+        return set_err(RL_E_INVALID, "scene belongs to a device context that no longer exists (created under another rl_init / rl_init_multi)");
+      int rc = rl::use_context(r->ctx);
+      if (rc != RL_OK) return rc;
+      for (int k = 0; k < rl_scene::N_STATUS; k++)
+        if (r->status_pending[k]) {
+          HIP_TRY(hipEventSynchronize(r->ev_status[k]));
+          rl::fold_status(r, k);
+        }
+    }
+    // rays: of the most recently enqueued render of this replica (summed over the replicas of a multi-GPU scene); flagged: every render since the last call
+    acc.rays += r->folded_rays, acc.flagged += r->folded_flagged;
+    g_last_slow_traces += r->folded_slow;
+    r->folded_rays = r->folded_flagged = r->folded_slow = 0, r->folded_seq = r->next_seq;
   }
   if (n > 1) rl::use_context(0);
   if (st) *st = acc;
@@ -1483,6 +1527,10 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
   std::memcpy(P.void_color, rc_.void_color, 24);
   P.out = (double *)d_out;
   P.stats = (unsigned long long *)(scene->d_scratch + 64);
+  {
+    int rco = order_after_previous(scene, stream);
+    if (rco != RL_OK) return rco;
+  }
   HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
   constexpr int NT = 256;
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_tris * sizeof(DevTri) + (size_t)P.n_guards * sizeof(RtcGuard);
@@ -1510,7 +1558,7 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
   else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
   HIP_TRY(hipGetLastError());
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
-  return RL_OK;
+  return mark_render_end(scene, stream);
 }
 }  // namespace rl
 
@@ -1526,6 +1574,7 @@ int rl_rtc_render_device(const rl_scene *scene, const rl_rtc_camera *cam, uint32
     if (st) std::memset(st, 0, sizeof *st);
     return RL_OK;
   }
+  std::lock_guard<std::mutex> lk(scene->mu);  // concurrent renders of one scene: see rl_scene::mu
   int rc = rl::rtc_render_launch(scene, cam, aa, row_first, row_step, d_out, stream, st != nullptr);
   if (rc != RL_OK) return rc;
   return st ? rl::collect_stats(scene, stream, st) : post_status(scene, stream);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,11 +89,24 @@ struct rl_scene {
   // per-scene scratch: [0] work counter (u32), [64..] 8 x u64 stats, [128..] scheduler debug counters
   unsigned char *d_scratch = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // status of the last asynchronous render (opt_stats == NULL): the 8 stats words copied to pinned host memory on the render's
-  // stream, and the event that follows the copy (rl_render_status waits for it)
-  unsigned long long *h_status = nullptr;
-  hipEvent_t ev_done = nullptr;
-  bool async_pending = false;
+  // Renders of one scene may be issued from several host threads and on several streams at once (the reference's Camera::render takes
+  // &self, camera.rs:122).  The scene owns ONE set of work buffers, so: `mu` serialises the host side (enqueueing a render, handing its
+  // status over), and a render enqueued on another stream than its predecessor first waits, on the device, for the predecessor's last
+  // kernel (`ev_last`) — concurrent callers are safe, their frames are rendered one after the other (each one fills the GPU anyway).
+  mutable std::mutex mu;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_last = nullptr;
+  bool has_last = false;
+  // status of the asynchronous renders (opt_stats == NULL) not yet collected by rl_render_status: a ring of N_STATUS slots of 8 stats
+  // words in pinned host memory, each behind the event that follows its copy; a slot that comes round again while still pending is
+  // waited for and folded into `folded_*`, so no panic-site count is ever lost
+  static constexpr int N_STATUS = 8;
+  unsigned long long *h_status = nullptr;  // [N_STATUS][8]
+  hipEvent_t ev_status[N_STATUS] = {};
+  bool status_pending[N_STATUS] = {};
+  unsigned long long status_seq[N_STATUS] = {};
+  int status_next = 0;
+  unsigned long long next_seq = 0, folded_seq = 0, folded_rays = 0, folded_flagged = 0, folded_slow = 0;
   // cost-sorted (LPT) two-phase render: per-pixel ChaCha word positions, per-tile cost and order
   uint32_t *d_pos = nullptr, *d_tile_cost = nullptr, *d_tile_order = nullptr, *d_tile_keys = nullptr, *d_tile_iota = nullptr;
   void *d_sort_temp = nullptr;
@@ -128,6 +142,9 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
 int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t aa, uint32_t row_first, uint32_t row_step, void *d_out, hipStream_t stream,
                       bool want_stats);
 int collect_stats(const rl_scene *scene, hipStream_t stream, rl_stats *st);  // RL_OK / RL_E_DEGENERATE / RL_E_DEVICE
+int post_status(const rl_scene *scene, hipStream_t stream);                  // asynchronous renders: next slot of the status ring
+int order_after_previous(const rl_scene *scene, hipStream_t stream);         // start of a render: device-side wait for the scene's previous render
+int mark_render_end(const rl_scene *scene, hipStream_t stream);              // end of a render's launch chain
 void add_stats(rl_stats *acc, const rl_stats &s);                             // sums counters, max of kernel_ms
 
 }  // namespace rl

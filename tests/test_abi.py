@@ -22,7 +22,7 @@ def test_header_symbols_all_exported(rl):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in rl_render.h but not exported"
     assert sorted(rl.api.RENDER_SYMBOLS) == syms
-    assert lib.rl_abi_version() == 5
+    assert lib.rl_abi_version() == 6
 
 
 def test_struct_layouts_match_header(rl):
