@@ -269,6 +269,10 @@ static double min_norm2_on_triangle(const double *a, const double *b, const doub
   return best;
 }
 
+// the eight-wide quantised form is A/B material (measured slower): built only when the experimental library asks for it
+static bool g_build_octo = false;
+void set_build_octo(bool on) { g_build_octo = on; }
+
 bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out) {
   out = FastGeneral{};
   if (rt.has_media) return false;  // a ConstantMedium draws from the RNG while the world is traversed: the reference's order is part of its result
@@ -598,6 +602,92 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     };
     out.qroot = fold(out.root);
   }
+  // ---- eight-wide form with quantised boxes (FastNodeO): fold until eight children are held (largest box first), then put every child's
+  // box on the node's 8-bit grid, rounded OUTWARDS — checked below in exact arithmetic (every term is a dyadic rational that binary64 holds)
+  out.onodes.clear();
+  out.oroot = out.root;
+  bool octo_ok = true;
+  if (g_build_octo && out.root != NONE && !(out.root & FASTG_LEAF)) {
+    struct Cand {
+      float box[6];
+      uint32_t e;
+    };
+    out.onodes.reserve(out.nodes.size() / 4 + 1);
+    std::function<uint32_t(uint32_t)> fold8 = [&](uint32_t n2) -> uint32_t {
+      Cand cs[8];
+      int nc = 0;
+      auto add = [&](const FastNodeG &nd, int side) {
+        std::memcpy(cs[nc].box, nd.box[side], sizeof cs[nc].box);
+        cs[nc].e = nd.child[side];
+        nc++;
+      };
+      add(out.nodes[n2], 0), add(out.nodes[n2], 1);
+      // the node's own extent fixes the grid pitch (extent / 255 per axis): a child is replaced by its two children only if those are
+      // still large against the pitch — a box of extent e on a grid of pitch p grows by up to 2p, and a subtree that is tiny next to a
+      // sibling (cfg 5: the 1000 x 1000 field of spheres next to the radius-1e6 ground) would otherwise be blown up to a grid cell
+      double ulo[3] = {INFINITY, INFINITY, INFINITY}, uhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int k = 0; k < 2; k++)
+        for (int ax = 0; ax < 3; ax++) ulo[ax] = std::fmin(ulo[ax], (double)cs[k].box[2 * ax]), uhi[ax] = std::fmax(uhi[ax], (double)cs[k].box[2 * ax + 1]);
+      const double pitch_max = std::fmax(std::fmax(uhi[0] - ulo[0], uhi[1] - ulo[1]), uhi[2] - ulo[2]) / 255.0;
+      auto big_enough = [&](const float *b) {
+        const double e = std::fmax(std::fmax((double)b[1] - b[0], (double)b[3] - b[2]), (double)b[5] - b[4]);
+        return e >= 16.0 * pitch_max;  // grows by <= 1/8 of its largest extent
+      };
+      while (nc < 8) {
+        int pick = -1;
+        double best = -1.0;
+        for (int k = 0; k < nc; k++) {
+          if (cs[k].e & FASTG_LEAF) continue;
+          const FastNodeG &cn = out.nodes[cs[k].e];
+          if (!(big_enough(cn.box[0]) && big_enough(cn.box[1]))) continue;
+          const float *b = cs[k].box;
+          double ex = (double)b[1] - b[0], ey = (double)b[3] - b[2], ez = (double)b[5] - b[4];
+          double area = ex * ey + ey * ez + ez * ex;
+          if (!(area <= best)) best = area, pick = k;
+        }
+        if (pick < 0) break;
+        const FastNodeG &nd = out.nodes[cs[pick].e];
+        cs[pick] = cs[nc - 1];
+        nc--;
+        add(nd, 0), add(nd, 1);
+      }
+      const uint32_t self = (uint32_t)out.onodes.size();
+      out.onodes.push_back(FastNodeO{});
+      uint32_t ch[8];
+      for (int k = 0; k < 8; k++) ch[k] = NONE;
+      for (int k = 0; k < nc; k++) ch[k] = (cs[k].e & FASTG_LEAF) ? cs[k].e : fold8(cs[k].e);
+      FastNodeO &q = out.onodes[self];
+      q.exps = 0;
+      for (int ax = 0; ax < 3; ax++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < nc; k++) lo = std::fmin(lo, (double)cs[k].box[2 * ax]), hi = std::fmax(hi, (double)cs[k].box[2 * ax + 1]);
+        if (!(std::fabs(lo) <= 1e30 && std::fabs(hi) <= 1e30)) octo_ok = false, lo = 0.0, hi = 1.0;
+        q.o[ax] = (float)lo;  // lo IS one of the children's float bounds: exact
+        // pitch 2^p with 255 * 2^p >= hi - lo; exponent kept in [-40, 60] (a ray's |1/d| is within [1e-30, 1e30]: products stay normal numbers)
+        int p = -40;
+        while (std::ldexp(255.0, p) < hi - lo && p < 60) p++;
+        if (std::ldexp(255.0, p) < hi - lo) octo_ok = false;
+        const double pitch = std::ldexp(1.0, p);
+        q.exps |= (uint32_t)(p + 127) << (8 * ax);
+        for (int k = 0; k < 8; k++) {
+          if (k >= nc) {
+            q.qlo[ax][k] = 255, q.qhi[ax][k] = 0;  // empty slot: inverted (the kernel also checks child != NONE)
+            continue;
+          }
+          const double l = (double)cs[k].box[2 * ax] - lo, h = (double)cs[k].box[2 * ax + 1] - lo;  // exact (binary32 operands in binary64)
+          double ql = std::floor(l / pitch), qh = std::ceil(h / pitch);  // division by a power of two: exact
+          ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql), qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
+          q.qlo[ax][k] = (uint8_t)ql, q.qhi[ax][k] = (uint8_t)qh;
+          // the stored planes, in exact arithmetic, must enclose the child's own box
+          if (!(lo + ql * pitch <= (double)cs[k].box[2 * ax] && lo + qh * pitch >= (double)cs[k].box[2 * ax + 1])) octo_ok = false;
+        }
+      }
+      for (int k = 0; k < 8; k++) q.child[k] = ch[k];
+      return self;
+    };
+    out.oroot = fold8(out.root);
+  }
+  if (!octo_ok) out.onodes.clear(), out.oroot = NONE;  // (non-finite / absurd extents: the four-wide form is walked instead)
   for (int ax = 0; ax < 3; ax++) out.center[ax] = (float)c[ax];
   out.r_safe = round_down(r_safe * 0.999 - 1e-6 * cabs);  // the device compares binary32 roundings of o and centre
   out.ok = out.r_safe > 0.0f;

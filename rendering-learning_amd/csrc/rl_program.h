@@ -148,6 +148,21 @@ struct alignas(16) FastNodeQ {
   uint32_t pad[4];
 };
 static_assert(sizeof(FastNodeQ) == 128, "FastNodeQ must be 128 B");
+// Eight-wide form with QUANTISED child boxes (round 3; EXPERIMENTAL: measured slower than the four-wide nodes, kept for A/B in
+// librl_render_exp.so with RL_FASTG_OCTO=1): the binary tree folded until a node holds up to eight children, their boxes stored
+// relative to the node's own lower corner on an 8-bit grid of power-of-two pitch per axis,
+//     plane(axis, k) = o[axis] + q[axis][k] * 2^(e[axis] - 127)        (qlo rounded down, qhi rounded up: the stored box CONTAINS the child's)
+// so that one dependent fetch (six 16-byte loads instead of seven) advances a ray THREE levels of the binary tree: a third fewer dependent
+// steps per ray than the four-wide nodes, half their L1 accesses.  Empty slots: child == NONE (and an inverted box).
+struct alignas(16) FastNodeO {
+  float o[3];          // lower corner of the node's box (the minimum over the children's boxes, exact)
+  uint32_t exps;       // e[0] | e[1] << 8 | e[2] << 16: biased binary32 exponents of the grid pitch (as_float(e << 23) = 2^(e - 127))
+  uint8_t qlo[3][8];   // [axis][child]
+  uint8_t qhi[3][8];
+  uint32_t child[8];
+  uint32_t pad[8];
+};
+static_assert(sizeof(FastNodeO) == 128, "FastNodeO must be 128 B");
 struct alignas(16) FastItem {
   uint32_t kind;     // 0 sphere, 1 planar
   uint32_t payload;  // sphere payload (index | SPH_MOVING | SPH_UV) or planar index
@@ -157,6 +172,8 @@ struct alignas(16) FastItem {
 struct FastGeneral {
   std::vector<FastNodeG> nodes;
   std::vector<FastNodeQ> qnodes;  // four-wide form of `nodes` (collapse_fast_general)
+  std::vector<FastNodeO> onodes;  // eight-wide form with quantised boxes (what the product kernel walks)
+  uint32_t oroot = NONE;
   std::vector<FastItem> items;
   std::vector<DevSphere> item_spheres;  // [item]: the sphere record of a sphere item (zero for planars), so that LEAF fetches item and sphere side by side
   std::vector<uint32_t> item_material;  // [item]: material index of the primitive
@@ -168,6 +185,7 @@ struct FastGeneral {
   bool ok = false;
 };
 bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out);
+void set_build_octo(bool on);  // experimental library, RL_FASTG_OCTO=1: also build FastGeneral::onodes
 
 // Returns RL_OK or RL_E_INVALID (err filled).
 int compile_rtiow(const rl_rtiow_scene_desc &d, RtiowProgram &out, std::string &err);

@@ -54,6 +54,7 @@ struct Switches {
   int coop_mode = -1;            // RL_COOP_MODE
   int general_regs = 512;        // RL_GENERAL_REGS (256 / 768: experimental library only)
   bool fastg512 = false;         // RL_FASTG512 (experimental library only)
+  int fastg_octo = 0;            // RL_FASTG_OCTO=1: the eight-wide quantised nodes instead of the four-wide ones (experimental library only)
   int general_nt = 512;          // RL_GENERAL_NT (768: experimental library only)
   double thin_permille = 0.0, prio_permille = 0.0;  // RL_THIN / RL_PRIO (experimental library only)
   int thin_shift = 2;            // RL_THIN_SHIFT
@@ -85,6 +86,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_COOP_MODE")) w.coop_mode = std::atoi(v);
   if (const char *v = std::getenv("RL_GENERAL_REGS")) w.general_regs = std::atoi(v);
   w.fastg512 = std::getenv("RL_FASTG512") != nullptr;
+  if (const char *v = std::getenv("RL_FASTG_OCTO")) w.fastg_octo = std::atoi(v);
   if (const char *v = std::getenv("RL_GENERAL_NT")) w.general_nt = std::atoi(v);
   if (const char *v = std::getenv("RL_THIN")) w.thin_permille = std::atof(v);
   if (const char *v = std::getenv("RL_PRIO")) w.prio_permille = std::atof(v);
@@ -93,6 +95,9 @@ void read_switches() {
   w.rtc_force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;
   if (const char *v = std::getenv("RL_RTC_FULL_REGS")) w.rtc_full_regs = std::atoi(v);
   g_sw = w;
+#ifdef RL_EXPERIMENTAL
+  rl::set_build_octo(w.fastg_octo != 0);
+#endif
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (kernel, device): set it when a launch needs more than any before it did
@@ -260,7 +265,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_steal_state), hipFree(s->d_steal_n), hipFree(s->d_fg_nodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_steal_state), hipFree(s->d_steal_n), hipFree(s->d_fg_nodes), hipFree(s->d_fg_onodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -274,6 +279,7 @@ static void destroy_one(rl_scene *s) {
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->ev_gather_read) hipEventDestroy(s->ev_gather_read);
+  hipFree(s->d_params);
   hipFree(s->d_wfg_pix), hipFree(s->d_wfg_ray), hipFree(s->d_wfg_q0), hipFree(s->d_wfg_q1), hipFree(s->d_wfg_qs), hipFree(s->d_wfg_ctl);
   if (s->h_wfg) hipHostFree(s->h_wfg);
   delete s;
@@ -479,7 +485,7 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && ((rc = upload(H->fast_nodes, &s->d_fast_nodes)) || (rc = upload(H->fast_leaf_boxes, &s->d_fast_leaf_boxes)))) ||
-      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
+      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.onodes, &s->d_fg_onodes)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
     destroy_one(s);
     return nullptr;
   }
@@ -745,6 +751,9 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
   P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_spheres = scene->d_fg_spheres, P.fg_material = scene->d_fg_material, P.fg_root = H.fg.qroot, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
+#ifdef RL_EXPERIMENTAL
+  P.fg_onodes = scene->d_fg_onodes, P.fg_oroot = H.fg.oroot;
+#endif
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;
@@ -778,6 +787,24 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;  // A/B only
     if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
+    HIP_TRY(hipGetLastError());
+    return RL_OK;
+  };
+  auto launch_ptr = [&](auto kern, int nt, size_t rng_bytes) -> int {  // kernels that take the parameter block by pointer (device copy)
+    rl_scene *ms = const_cast<rl_scene *>(scene);
+    if (!ms->d_params) HIP_TRY(hipMalloc((void **)&ms->d_params, 2 * sizeof(RtiowParams)));
+    // two slots: the cost-sorted render launches twice with different parameters, both enqueued before the first one runs
+    RtiowParams *slot = (RtiowParams *)ms->d_params + (ms->params_slot++ & 1);
+    HIP_TRY(hipMemcpyAsync(slot, &P, sizeof(RtiowParams), hipMemcpyHostToDevice, stream));
+    size_t lds = rng_bytes;
+    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
+    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nt > 2048) per_cu = 2048 / nt;
+    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
+    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;
+    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, (const RtiowParams *)slot);
     HIP_TRY(hipGetLastError());
     return RL_OK;
   };
@@ -899,17 +926,21 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
         constexpr int NT = 512, SD = 40;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
-        rc = launch(rtiow_fast_general_kernel<NT, SD, true>, NT, rb, false);
+        rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, true>, NT, rb);
 #ifdef RL_EXPERIMENTAL
       } else if (g_sw.fastg512) {
         constexpr int NT = 512, SD = 40;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
-        rc = launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+        rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, false>, NT, rb);
 #endif
       } else {  // 768 lanes per CU (3 waves per SIMD hide more of the node-fetch latency), 20-entry stacks: 208 B of LDS per lane
         constexpr int NT = 768, SD = 20;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
-        rc = launch(rtiow_fast_general_kernel<NT, SD, false>, NT, rb, false);
+#ifdef RL_EXPERIMENTAL  // eight-wide quantised nodes (FastNodeO): cow scene 6.1 -> 3.8 steps per ray but -3.5 %, cfg 5 16.5 -> 13.9 steps, +10 % LEAF visits, -15 %
+        if (!H.fg.onodes.empty() && g_sw.fastg_octo != 0) rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, false, true>, NT, rb);
+        else
+#endif
+          rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, false>, NT, rb);
       }
     } else if (variant == 4) {
       // 512 lanes per CU (2 waves per SIMD): the kernel needs ~200 VGPRs (~260 with the sin / Perlin / acos / atan2 code of

@@ -163,8 +163,12 @@ __device__ __forceinline__ void fastg_sphere_hit(const DevSphere &s, uint32_t pa
 // and spheres behind 4 MB of L2 per XCD) +6 ... 8 %.  Also measured, and dropped: a 10-bit lower bound of the entry distance in every stack
 // entry, so that pop() can skip entries that have fallen behind the closest hit (cfg 4 -10 %, cfg 5 -6 %: the skipped visits are worth less
 // than the dependent LDS round trips of the skipping loop).
-template <int NT, int SD, bool TRANS>
-__global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
+// OCTO: the eight-wide nodes with quantised boxes (FastNodeO) instead of the four-wide ones (FastNodeQ)
+template <int NT, int SD, bool TRANS, bool OCTO = false>
+__global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParams *__restrict__ Pp) {
+  // the parameter block is read from memory where it is needed (uniform addresses: scalar loads through the constant cache) instead of
+  // arriving by value: by value every field that is live anywhere is loaded at kernel entry and pins SGPRs for the kernel's life time
+  const RtiowParams &P = *Pp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;                                   // [16][NT]
@@ -240,7 +244,11 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
       grow = P.fg_pad_k * L * L * fmaxf(fmaxf(fabsf(ra32.invx), fabsf(ra32.invy)), fabsf(ra32.invz));
       if (!(grow < FINF)) amb = true;
     }
+#ifdef RL_EXPERIMENTAL
+    go(amb ? NONE : (OCTO ? P.fg_oroot : P.fg_root));
+#else
     go(amb ? NONE : P.fg_root);
+#endif
   };
 
   for (;;) {
@@ -265,50 +273,135 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(RtiowParams P) {
 #ifdef RL_FASTG_VERIFY
           c_steps++;
 #endif
-          const float c32 = unsafe ? FINF : (float)closest;
-          auto missed = [&](float b0, float b1, float b2, float b3, float b4, float b5, float &tmin) {
-            float t0x = fmaf(b0, ra32.invx, -ra32.oix), t1x = fmaf(b1, ra32.invx, -ra32.oix);
-            float t0y = fmaf(b2, ra32.invy, -ra32.oiy), t1y = fmaf(b3, ra32.invy, -ra32.oiy);
-            float t0z = fmaf(b4, ra32.invz, -ra32.oiz), t1z = fmaf(b5, ra32.invz, -ra32.oiz);
-            tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)) - grow, 1e-10f);
-            float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) + grow, c32);
-            float diff = tmax - tmin;
-            float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
-            return diff < -thresh;
-          };
-          auto push = [&](uint32_t e) {
-            if (sp < (uint32_t)SD) s_stack[(size_t)sp * NT + tid] = e, sp++;
-            else amb = true;  // more pending children than the stack holds: the reference's order decides
-          };
-          const Float4 *nd = (const Float4 *)(nodes + pc);
-          // Measured and dropped (round 3, RL_TUNE experiment bits): the node's first 16 bytes alone, then an s_waitcnt, then the other six
-          // loads (so that they find the line in L1 instead of pending): cfg 5 -2.5 %, cfg 4 -1 %; the same 112 bytes as fourteen 8-byte
-          // loads (twice the L1 accesses): cfg 5 -9.5 %, cfg 4 -3.5 % — the L1 access rate is a second-order cost, not the bound.
-          const Float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-          const uint4 ch = *(const uint4 *)(nd + 6);
-          float k0, k1, k2, k3;
-          const bool h0 = !missed(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, k0);  // slot 0 and 1 are never empty
-          const bool h1 = !missed(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, k1);
-          const bool h2 = !missed(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, k2) && ch.z != NONE;
-          const bool h3 = !missed(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, k3) && ch.w != NONE;
-          const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-          k0 = h0 ? k0 : FINF, k1 = h1 ? k1 : FINF, k2 = h2 ? k2 : FINF, k3 = h3 ? k3 : FINF;
-          uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-          // entry-distance order (a sorting network: the hits end up first, nearest first); keys carry their hit bit in the
-          // lowest mantissa bit so that a hit at +inf (non-finite arithmetic: not certainly missed) still sorts before a miss
-          uint32_t u0 = (__float_as_uint(k0) & ~1u) | (h0 ? 0u : 1u), u1 = (__float_as_uint(k1) & ~1u) | (h1 ? 0u : 1u);
-          uint32_t u2 = (__float_as_uint(k2) & ~1u) | (h2 ? 0u : 1u), u3 = (__float_as_uint(k3) & ~1u) | (h3 ? 0u : 1u);
-          auto cex = [&](uint32_t &ka, uint32_t &kb, uint32_t &ca, uint32_t &cb) {  // keys are non-negative floats: integer order = float order
-            const bool sw = kb < ka;
-            const uint32_t tk = sw ? kb : ka, tc = sw ? cb : ca;
-            kb = sw ? ka : kb, cb = sw ? ca : cb;
-            ka = tk, ca = tc;
-          };
-          cex(u0, u1, c0, c1), cex(u2, u3, c2, c3), cex(u0, u2, c0, c2), cex(u1, u3, c1, c3), cex(u1, u2, c1, c2);
-          if (nh >= 4) push(c3);
-          if (nh >= 3) push(c2);
-          if (nh >= 2) push(c1);
-          go(nh ? c0 : pop());
+#ifdef RL_EXPERIMENTAL
+          if (OCTO) {
+            const float c32 = unsafe ? FINF : (float)closest;
+            auto push = [&](uint32_t e) {
+              if (sp < (uint32_t)SD) s_stack[(size_t)sp * NT + tid] = e, sp++;
+              else amb = true;  // more pending children than the stack holds: the reference's order decides
+            };
+            // ---- one FastNodeO: eight children, boxes on the node's 8-bit grid.  For child k and axis x the stored planes are
+            // B = o_x + q * S_x (S_x a power of two), so t = (B - ray.o_x) / d_x = q * a_x + b_x with a_x = S_x / d_x (exact scaling of the
+            // ray's binary32 reciprocal) and b_x = (o_x - ray.o_x) / d_x = fma(o_x, inv_x, -oi_x): TWO instructions per plane (byte -> float,
+            // fma), and the near / far plane of a slab is known from the sign of d_x — no per-axis min / max.
+            // Error against the exact quotient, with ray_aux32_direct's bounds (inv32 = (1/d)(1 + e), |e| <= 3u; oi32 within 5u |o/d|; u = 2^-24):
+            //   |q a - q S/d| <= 3u |q S/d|,  |b'' - b| <= 3u |o_x/d| (product) + 5u |o/d| + u |b|,  one rounding in the final fma:
+            //   |t'' - t| <= 4u |t''| + 7u |b_x| + 8u max|o/d|   (|q S/d| <= |t| + |b|, |o_x/d| <= |b| + |o/d|).
+            // The first and last terms are inside the threshold every reject-only test of this kernel already uses (6u |t| + 9u max|o/d| per end);
+            // the middle one is folded into the planes themselves: the near plane is evaluated with b - 10u |b|, the far one with b + 10u |b|
+            // (per node and axis, three instructions), so each computed interval CONTAINS the exact one whatever the other axes do — an axis
+            // the ray runs nearly parallel to has huge |b| and huge errors, and simply never decides (its near / far are -/+ huge).
+            const uint4 *nd = (const uint4 *)(P.fg_onodes + pc);
+            const uint4 h = nd[0], qa = nd[1], qb = nd[2], qc = nd[3], ca = nd[4], cb = nd[5];
+            float nax, nbn, nbf, nay, nbyn, nbyf, naz, nbzn, nbzf;
+            auto axis = [&](uint32_t obits, uint32_t ebits, float inv, float oi, float &a, float &bn, float &bf) {
+              a = __uint_as_float((ebits & 0xFFu) << 23) * inv;
+              const float b = fmaf(__uint_as_float(obits), inv, -oi);
+              const float c = fabsf(b) * 5.9604644775390625e-07f;  // 10u |b|
+              bn = b - c, bf = b + c;
+              // outside the range in which q a + b is a faithful sum (products near the ends of binary32): the axis does not constrain
+              const bool ok = fabsf(a) > 1e-30f && fabsf(a) < 1e27f && fabsf(b) < 1e30f;
+              a = ok ? a : 0.0f, bn = ok ? bn : -FINF, bf = ok ? bf : FINF;
+            };
+            axis(h.x, h.w, ra32.invx, ra32.oix, nax, nbn, nbf);
+            axis(h.y, h.w >> 8, ra32.invy, ra32.oiy, nay, nbyn, nbyf);
+            axis(h.z, h.w >> 16, ra32.invz, ra32.oiz, naz, nbzn, nbzf);
+            // the planes a ray meets first / last on each axis: qlo / qhi swapped for negative directions (eight children = two words per axis)
+            const bool ngx = ra32.invx < 0.0f, ngy = ra32.invy < 0.0f, ngz = ra32.invz < 0.0f;
+            const uint32_t lx0 = qa.x, lx1 = qa.y, ly0 = qa.z, ly1 = qa.w, lz0 = qb.x, lz1 = qb.y;
+            const uint32_t hx0 = qb.z, hx1 = qb.w, hy0 = qc.x, hy1 = qc.y, hz0 = qc.z, hz1 = qc.w;
+            const uint32_t nx0 = ngx ? hx0 : lx0, nx1 = ngx ? hx1 : lx1, fx0 = ngx ? lx0 : hx0, fx1 = ngx ? lx1 : hx1;
+            const uint32_t ny0 = ngy ? hy0 : ly0, ny1 = ngy ? hy1 : ly1, fy0 = ngy ? ly0 : hy0, fy1 = ngy ? ly1 : hy1;
+            const uint32_t nz0 = ngz ? hz0 : lz0, nz1 = ngz ? hz1 : lz1, fz0 = ngz ? lz0 : hz0, fz1 = ngz ? lz1 : hz1;
+            uint32_t key[8];
+            int nh = 0;
+            auto child = [&](int k, float qnx, float qfx, float qny, float qfy, float qnz, float qfz, uint32_t cid) {
+              const float tn = fmaxf(fmaxf(fmaf(qnx, nax, nbn), fmaf(qny, nay, nbyn)), fmaf(qnz, naz, nbzn));
+              const float tf = fminf(fminf(fmaf(qfx, nax, nbf), fmaf(qfy, nay, nbyf)), fmaf(qfz, naz, nbzf));
+              const float tmin = fmaxf(tn - grow, 1e-10f), tmax = fminf(tf + grow, c32);
+              const float diff = tmax - tmin;
+              const float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
+              const bool hit = !(diff < -thresh) && cid != NONE;  // NaN arithmetic: not certainly missed
+              nh += hit ? 1 : 0;
+              // sort key: entry distance (non-negative float: integer order = float order), bit 3 = "missed", low three bits = the slot
+              key[k] = hit ? ((__float_as_uint(tmin) & ~15u) | (uint32_t)k) : (0x7F800008u | (uint32_t)k);
+            };
+#define RL_UB(w, i) ((float)(((w) >> (8 * (i))) & 0xFFu))  /* v_cvt_f32_ubyte<i> */
+            child(0, RL_UB(nx0, 0), RL_UB(fx0, 0), RL_UB(ny0, 0), RL_UB(fy0, 0), RL_UB(nz0, 0), RL_UB(fz0, 0), ca.x);
+            child(1, RL_UB(nx0, 1), RL_UB(fx0, 1), RL_UB(ny0, 1), RL_UB(fy0, 1), RL_UB(nz0, 1), RL_UB(fz0, 1), ca.y);
+            child(2, RL_UB(nx0, 2), RL_UB(fx0, 2), RL_UB(ny0, 2), RL_UB(fy0, 2), RL_UB(nz0, 2), RL_UB(fz0, 2), ca.z);
+            child(3, RL_UB(nx0, 3), RL_UB(fx0, 3), RL_UB(ny0, 3), RL_UB(fy0, 3), RL_UB(nz0, 3), RL_UB(fz0, 3), ca.w);
+            child(4, RL_UB(nx1, 0), RL_UB(fx1, 0), RL_UB(ny1, 0), RL_UB(fy1, 0), RL_UB(nz1, 0), RL_UB(fz1, 0), cb.x);
+            child(5, RL_UB(nx1, 1), RL_UB(fx1, 1), RL_UB(ny1, 1), RL_UB(fy1, 1), RL_UB(nz1, 1), RL_UB(fz1, 1), cb.y);
+            child(6, RL_UB(nx1, 2), RL_UB(fx1, 2), RL_UB(ny1, 2), RL_UB(fy1, 2), RL_UB(nz1, 2), RL_UB(fz1, 2), cb.z);
+            child(7, RL_UB(nx1, 3), RL_UB(fx1, 3), RL_UB(ny1, 3), RL_UB(fy1, 3), RL_UB(nz1, 3), RL_UB(fz1, 3), cb.w);
+#undef RL_UB
+            // Batcher's odd-even merge sort of the eight keys (19 compare-exchanges, min / max on unsigned words): hits first, nearest first
+            auto cex = [&](int i, int j) {
+              const uint32_t lo = min(key[i], key[j]), hi = max(key[i], key[j]);
+              key[i] = lo, key[j] = hi;
+            };
+            cex(0, 1), cex(2, 3), cex(4, 5), cex(6, 7), cex(0, 2), cex(1, 3), cex(4, 6), cex(5, 7), cex(1, 2), cex(5, 6);
+            cex(0, 4), cex(1, 5), cex(2, 6), cex(3, 7), cex(2, 4), cex(3, 5), cex(1, 2), cex(3, 4), cex(5, 6);
+            auto child_of = [&](uint32_t kk) -> uint32_t {  // the child id in slot (kk & 7)
+              const uint32_t s = kk & 7u;
+              const uint32_t a0 = (s & 1u) ? ca.y : ca.x, a1 = (s & 1u) ? ca.w : ca.z, b0 = (s & 1u) ? cb.y : cb.x, b1 = (s & 1u) ? cb.w : cb.z;
+              const uint32_t a = (s & 2u) ? a1 : a0, b = (s & 2u) ? b1 : b0;
+              return (s & 4u) ? b : a;
+            };
+            // the farther hits wait on the stack, farthest first
+#pragma unroll
+            for (int j = 7; j >= 1; j--)
+              if (nh > j) push(child_of(key[j]));
+            go(nh ? child_of(key[0]) : pop());
+          } else
+#endif
+          {
+            const float c32 = unsafe ? FINF : (float)closest;
+            auto missed = [&](float b0, float b1, float b2, float b3, float b4, float b5, float &tmin) {
+              float t0x = fmaf(b0, ra32.invx, -ra32.oix), t1x = fmaf(b1, ra32.invx, -ra32.oix);
+              float t0y = fmaf(b2, ra32.invy, -ra32.oiy), t1y = fmaf(b3, ra32.invy, -ra32.oiy);
+              float t0z = fmaf(b4, ra32.invz, -ra32.oiz), t1z = fmaf(b5, ra32.invz, -ra32.oiz);
+              tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)) - grow, 1e-10f);
+              float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) + grow, c32);
+              float diff = tmax - tmin;
+              float thresh = fmaf(tmin + fabsf(tmax), 7.152557373046875e-07f, ra32.slack);  // 12u(|tmin|+|tmax|) + slack (ray_aux32_direct)
+              return diff < -thresh;
+            };
+            auto push = [&](uint32_t e) {
+              if (sp < (uint32_t)SD) s_stack[(size_t)sp * NT + tid] = e, sp++;
+              else amb = true;  // more pending children than the stack holds: the reference's order decides
+            };
+            const Float4 *nd = (const Float4 *)(nodes + pc);
+            // Measured and dropped (round 3, RL_TUNE experiment bits): the node's first 16 bytes alone, then an s_waitcnt, then the other six
+            // loads (so that they find the line in L1 instead of pending): cfg 5 -2.5 %, cfg 4 -1 %; the same 112 bytes as fourteen 8-byte
+            // loads (twice the L1 accesses): cfg 5 -9.5 %, cfg 4 -3.5 % — the L1 access rate is a second-order cost, not the bound.
+            const Float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+            const uint4 ch = *(const uint4 *)(nd + 6);
+            float k0, k1, k2, k3;
+            const bool h0 = !missed(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, k0);  // slot 0 and 1 are never empty
+            const bool h1 = !missed(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, k1);
+            const bool h2 = !missed(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, k2) && ch.z != NONE;
+            const bool h3 = !missed(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, k3) && ch.w != NONE;
+            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            k0 = h0 ? k0 : FINF, k1 = h1 ? k1 : FINF, k2 = h2 ? k2 : FINF, k3 = h3 ? k3 : FINF;
+            uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+            // entry-distance order (a sorting network: the hits end up first, nearest first); keys carry their hit bit in the
+            // lowest mantissa bit so that a hit at +inf (non-finite arithmetic: not certainly missed) still sorts before a miss
+            uint32_t u0 = (__float_as_uint(k0) & ~1u) | (h0 ? 0u : 1u), u1 = (__float_as_uint(k1) & ~1u) | (h1 ? 0u : 1u);
+            uint32_t u2 = (__float_as_uint(k2) & ~1u) | (h2 ? 0u : 1u), u3 = (__float_as_uint(k3) & ~1u) | (h3 ? 0u : 1u);
+            auto cex = [&](uint32_t &ka, uint32_t &kb, uint32_t &ca, uint32_t &cb) {  // keys are non-negative floats: integer order = float order
+              const bool sw = kb < ka;
+              const uint32_t tk = sw ? kb : ka, tc = sw ? cb : ca;
+              kb = sw ? ka : kb, cb = sw ? ca : cb;
+              ka = tk, ca = tc;
+            };
+            cex(u0, u1, c0, c1), cex(u2, u3, c2, c3), cex(u0, u2, c0, c2), cex(u1, u3, c1, c3), cex(u1, u2, c1, c2);
+            if (nh >= 4) push(c3);
+            if (nh >= 3) push(c2);
+            if (nh >= 2) push(c1);
+            go(nh ? c0 : pop());
+          }
         }
         if (__popcll(__ballot(state == ST_TRAV)) < floor_n) break;
       }

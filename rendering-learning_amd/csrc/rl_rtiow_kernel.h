@@ -39,6 +39,10 @@ struct RtiowParams {
   const uint32_t *fg_material;   // [item] material index
   const FastItem *fg_items;
   uint32_t fg_root;
+#ifdef RL_EXPERIMENTAL
+  const FastNodeO *fg_onodes;  // eight-wide quantised form (FastNodeO) and its root entry (A/B)
+  uint32_t fg_oroot;
+#endif
   float fg_center[3], fg_rsafe2;  // r_safe squared
   float fg_radius, fg_pad_k;      // far-origin rays: box growth = fg_pad_k * (distance + fg_radius)^2 (rl_rtiow_fastgen.h start_ray)
   rl_rtiow_camera cam;

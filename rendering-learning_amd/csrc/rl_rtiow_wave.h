@@ -346,6 +346,10 @@ __device__ __forceinline__ void rtiow_steal_loop(const RtiowParams &P, unsigned 
 
 // STEAL (LDS_SCENE = 4, counter-free, the cost-sorted resume launch of a small shard): lanes hand a pixel over, at a sample boundary, to
 // a wave that asks for it (P.steal_state), and a wave without work left asks — see rtiow_steal_loop
+// (The parameter block arrives BY VALUE.  Measured in round 3: reading it from a device copy instead — scalar loads where a field is needed —
+// removes every spill of the <1024, 4, false> instantiation (5 VGPRs / 75 SGPRs / 20 B of scratch -> 0 / 0 / 0) and is 1.2 % SLOWER
+// (6625 against 6707 Mrays/s; the work-stealing instantiation 212 against 178 ms on the 1/8 shard): the v_readlane restores sit in block
+// preambles, the scalar loads would sit in the blocks.)
 template <int NT, int LDS_SCENE, bool STATS, bool STEAL = false>
 __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

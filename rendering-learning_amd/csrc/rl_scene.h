@@ -63,6 +63,7 @@ struct rl_scene {
   uint32_t *d_steal_state = nullptr, *d_steal_n = nullptr;  // work stealing on small shards (RtiowParams::steal_state)
   size_t steal_pix = 0;
   rl::FastNodeQ *d_fg_nodes = nullptr;
+  rl::FastNodeO *d_fg_onodes = nullptr;
   rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_fg_spheres = nullptr;
   uint32_t *d_fg_material = nullptr;
@@ -122,6 +123,8 @@ struct rl_scene {
   uint32_t *d_wfg_q0 = nullptr, *d_wfg_q1 = nullptr, *d_wfg_qs = nullptr, *d_wfg_ctl = nullptr;
   size_t wfg_pix_cap = 0, wfg_slot_cap = 0;
   void *h_wfg = nullptr;
+  void *d_params = nullptr;  // device copies (two slots) of the parameter block for the kernels that take it by pointer
+  unsigned params_slot = 0;
   uint32_t *d_pix_rays = nullptr;  // debug (tools/): per-pixel ray counts of the last counting render
   void *exp = nullptr;             // experimental kernels' work buffers (rl_render.hip, RL_EXPERIMENTAL builds only)
 };
