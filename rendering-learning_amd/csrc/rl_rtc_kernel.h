@@ -240,8 +240,10 @@ __device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *
   return atten;
 }
 
-template <int NT, bool LDS_SCENE>
-__global__ void __launch_bounds__(NT) rtc_kernel(RtcParams P) {
+// REGS_FOR: the workgroup size the register budget is computed for (NT: one wave per SIMD and up to 512 registers, 2 NT / 3 NT / 4 NT: the
+// budget of two / three / four waves per SIMD)
+template <int NT, bool LDS_SCENE, int REGS_FOR = NT>
+__global__ void __launch_bounds__(REGS_FOR) rtc_kernel(RtcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const DevOp *ops = P.ops;
