@@ -734,21 +734,19 @@ static int render_wfg(const rl_scene *scene, RtiowParams &P, uint32_t nrows, hip
 
 #endif
 
-namespace rl {
-int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, void *d_out,
-                        hipStream_t stream, bool want_stats) {
+// The parameter block of one render (what every RTIOW kernel receives): scene pointers, derived camera, ChaCha key, shard geometry.
+static int fill_rtiow_params(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, uint32_t nrows, void *d_out,
+                             bool want_stats, RtiowParams &P, uint64_t &slots) {
   const RtiowProgram &rt = scene->rt();
   const HostRtiow &H = *scene->hrt;
-  uint32_t H_ = cam->image_height, W = cam->image_width;
-  uint32_t nrows = row_first < H_ ? (H_ - row_first + row_step - 1) / row_step : 0;
-  RtiowParams P{};
+  const uint32_t W = cam->image_width;
+  P = RtiowParams{};
   P.ops = scene->d_ops, P.spheres = scene->d_spheres, P.sphere_material = scene->d_sphere_material;
   P.planars = scene->d_planars, P.translates = scene->d_translates, P.transforms = scene->d_transforms;
   P.materials = scene->d_materials, P.textures = scene->d_textures, P.images = scene->d_images, P.image_pool = scene->d_image_pool, P.perlins = scene->d_perlins, P.media = scene->d_media;
   P.n_ops = (uint32_t)rt.ops.size(), P.n_spheres = (uint32_t)rt.spheres.size();
   P.lops = scene->d_lops, P.entry0 = H.entry0, P.sphere_flat = scene->d_sphere_flat;
-  const uint32_t n_cops = (uint32_t)H.cops.size();
-  P.cops = scene->d_cops, P.n_cops = n_cops, P.centry0 = H.centry0, P.movbits = scene->d_movbits;
+  P.cops = scene->d_cops, P.n_cops = (uint32_t)H.cops.size(), P.centry0 = H.centry0, P.movbits = scene->d_movbits;
   P.fast_nodes = scene->d_fast_nodes, P.n_fast_inner = (uint32_t)H.fast_nodes.size(), P.fast_root = H.fast_root;
   P.fg_nodes = scene->d_fg_nodes, P.fg_items = scene->d_fg_items, P.fg_spheres = scene->d_fg_spheres, P.fg_material = scene->d_fg_material, P.fg_root = H.fg.qroot, P.fg_rsafe2 = H.fg.r_safe * H.fg.r_safe * 0.9999f;  // binary32 evaluation on the device: keep a margin
 #ifdef RL_EXPERIMENTAL
@@ -761,7 +759,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.first_sample = first_sample;
   P.row_first = row_first, P.row_step = row_step, P.nrows = nrows;
   P.tiles_x = (W + 7) / 8;
-  uint64_t slots = (uint64_t)P.tiles_x * ((nrows + 7) / 8) * 64ull;
+  slots = (uint64_t)P.tiles_x * ((nrows + 7) / 8) * 64ull;
   if (slots >= 0xFFFF0000ull) return set_err(RL_E_INVALID, "image too large");
   P.n_slots = (uint32_t)slots;
   P.work_counter = (uint32_t *)scene->d_scratch;
@@ -770,51 +768,28 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
   P.k8u = 8.8817841970012523e-16;
   P.tune[0] = g_sw.tune[0], P.tune[1] = g_sw.tune[1], P.tune[2] = g_sw.tune[2], P.tune[3] = g_sw.tune[3];
   P.pix_rays = want_stats ? scene->d_pix_rays : nullptr;
+  return RL_OK;
+}
 
-  {
-    int rco = order_after_previous(scene, stream);
-    if (rco != RL_OK) return rco;
-  }
-  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
-  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
-  auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
-    size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
-    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
-    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));  // persistent lanes: as many workgroups as stay resident
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu * nt > 2048) per_cu = 2048 / nt;
-    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
-    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;  // A/B only
-    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
-    HIP_TRY(hipGetLastError());
-    return RL_OK;
-  };
-  auto launch_ptr = [&](auto kern, int nt, size_t rng_bytes) -> int {  // kernels that take the parameter block by pointer (device copy)
-    rl_scene *ms = const_cast<rl_scene *>(scene);
-    if (!ms->d_params) HIP_TRY(hipMalloc((void **)&ms->d_params, 2 * sizeof(RtiowParams)));
-    // two slots: the cost-sorted render launches twice with different parameters, both enqueued before the first one runs
-    RtiowParams *slot = (RtiowParams *)ms->d_params + (ms->params_slot++ & 1);
-    HIP_TRY(hipMemcpyAsync(slot, &P, sizeof(RtiowParams), hipMemcpyHostToDevice, stream));
-    size_t lds = rng_bytes;
-    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
-    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu * nt > 2048) per_cu = 2048 / nt;
-    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
-    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;
-    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, (const RtiowParams *)slot);
-    HIP_TRY(hipGetLastError());
-    return RL_OK;
-  };
+// Which kernel renders this frame (RL_RTIOW_KERNEL / rl_debug_set_rtiow_variant force one where the scene qualifies), and the LDS bytes of its scene part.
+struct RtiowChoice {
+  int variant = 0;
+  bool general = false;
+  size_t compact_bytes = 0, fast_bytes = 0, scene_bytes = 0;
+  bool fits_fast = false;
+};
+static int choose_rtiow_variant(const rl_scene *scene, const rl_rtiow_camera *cam, const RtiowParams &P, uint32_t nrows, bool want_stats, RtiowChoice &out) {
+  const RtiowProgram &rt = scene->rt();
+  const HostRtiow &H = *scene->hrt;
+  const uint32_t W = cam->image_width, n_cops = P.n_cops;
+  const size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
   // ---- kernel variant.  The PRODUCT library carries, for sphere-only worlds, the four layouts the automatic choice below can reach
   // (1029 fast traversal / 1027 guarded compact ops / 1025 linked ops in LDS / 1024 scene through L2), the cooperative kernel (1033) and
   // the nested-loop all-primitives kernel (2: the A/B reference the tests compare against); for general worlds 1031 (fast traversal) and
   // 4 (reference order).  Every other instantiation (wave256 / 512 / 768, whole-scene-in-LDS layouts, v1, other register budgets,
   // pool / wave2 / wavefront) is A/B material and lives in librl_render_exp.so (make exp).
   int variant = g_sw.rtiow_variant;
-  bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
+  const bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
   // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: the reference-order kernels evaluate it (the
   // wave-scheduled one as a scope of the threaded program, the nested-loop one by recursion: RL_RTIOW_KERNEL=general); no fast traversal
   if (rt.has_media && variant != 2) variant = 4;
@@ -870,6 +845,69 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     // pixels on the wave-scheduled kernel with work stealing is as fast or faster (37 k: 173 ms, 90 k: 170 ms; tools/steal_ab.py).
     if (variant == 1029 && !want_stats && g_sw.coop_small && (uint64_t)nrows * W <= (uint64_t)g_cus * 16u * 10u) variant = 1033;
   }
+  out.variant = variant, out.general = general, out.compact_bytes = compact_bytes, out.fast_bytes = fast_bytes, out.scene_bytes = scene_bytes, out.fits_fast = fits_fast;
+  return RL_OK;
+}
+
+namespace rl {
+int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint64_t first_sample, uint32_t row_first, uint32_t row_step, void *d_out,
+                        hipStream_t stream, bool want_stats) {
+  const RtiowProgram &rt = scene->rt();
+  const HostRtiow &H = *scene->hrt;
+  (void)H;  // (experimental builds read more of it)
+  uint32_t H_ = cam->image_height, W = cam->image_width;
+  uint32_t nrows = row_first < H_ ? (H_ - row_first + row_step - 1) / row_step : 0;
+  RtiowParams P;
+  uint64_t slots = 0;
+  {
+    int rcp = fill_rtiow_params(scene, cam, first_sample, row_first, row_step, nrows, d_out, want_stats, P, slots);
+    if (rcp != RL_OK) return rcp;
+  }
+
+  {
+    int rco = order_after_previous(scene, stream);
+    if (rco != RL_OK) return rco;
+  }
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
+  size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
+  auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
+    size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
+    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
+    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));  // persistent lanes: as many workgroups as stay resident
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nt > 2048) per_cu = 2048 / nt;
+    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
+    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;  // A/B only
+    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, P);
+    HIP_TRY(hipGetLastError());
+    return RL_OK;
+  };
+  auto launch_ptr = [&](auto kern, int nt, size_t rng_bytes) -> int {  // kernels that take the parameter block by pointer (device copy)
+    rl_scene *ms = const_cast<rl_scene *>(scene);
+    if (!ms->d_params) HIP_TRY(hipMalloc((void **)&ms->d_params, 2 * sizeof(RtiowParams)));
+    // two slots: the cost-sorted render launches twice with different parameters, both enqueued before the first one runs
+    RtiowParams *slot = (RtiowParams *)ms->d_params + (ms->params_slot++ & 1);
+    HIP_TRY(hipMemcpyAsync(slot, &P, sizeof(RtiowParams), hipMemcpyHostToDevice, stream));
+    size_t lds = rng_bytes;
+    uint32_t blocks = (uint32_t)((slots + nt - 1) / nt);
+    uint32_t per_cu = (uint32_t)(g_lds_max / (lds ? lds : 1));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * nt > 2048) per_cu = 2048 / nt;
+    if (blocks > (uint32_t)g_cus * per_cu) blocks = (uint32_t)g_cus * per_cu;
+    if (g_sw.blocks_cap >= 1 && g_sw.blocks_cap < blocks) blocks = g_sw.blocks_cap;
+    if (ensure_lds_attr((const void *)kern, lds) != 0) return set_err(RL_E_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(nt), lds, stream, (const RtiowParams *)slot);
+    HIP_TRY(hipGetLastError());
+    return RL_OK;
+  };
+  RtiowChoice choice;
+  {
+    int rcv = choose_rtiow_variant(scene, cam, P, nrows, want_stats, choice);
+    if (rcv != RL_OK) return rcv;
+  }
+  const int variant = choice.variant;
+  const size_t compact_bytes = choice.compact_bytes, fast_bytes = choice.fast_bytes;
   bool steal = false;  // set for the resume launch of a small shard (variant 1029)
   auto launch_coop = [&](const uint32_t *d_pixels, uint32_t n_pixels) -> int {
     constexpr int NW = 4;
