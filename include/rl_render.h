@@ -263,6 +263,15 @@ int rl_rtiow_render_device(const rl_scene *, const rl_rtiow_camera *, uint64_t f
  * if a reference panic site (camera.rs:86, material.rs:151, vec3.rs:220, ...) was reached, else RL_OK. */
 int rl_render_status(const rl_scene *, rl_stats *opt_stats);
 
+/* Progress of the RTIOW render that is executing on this scene — the reference logs "Scanline-equivalents remaining" once per `image_width`
+ * finished pixels (camera.rs:176-184); a host that wants that line polls this from another thread.  pixels_claimed: pixel slots the
+ * kernel's lanes have taken so far in the launch that is running; pixels_total: slots of that launch (the shard's pixels rounded up to
+ * 8 x 8 tiles); phase: a render of >= 64 samples per pixel is two launches (0: samples [0, 8) of every pixel, 1: the rest).  Never waits:
+ * the FIRST call switches progress counting on for the renders enqueued after it (their work counters then live in pinned host memory the
+ * kernels reach over PCIe, one atomic per wave per 64 pixels) and reports zeros; later calls are two host loads.  Frames of at most ~41 k
+ * pixels (cooperative kernel) and counting renders report through the same words.  All three outputs are optional (NULL). */
+int rl_rtiow_render_progress(const rl_scene *, uint64_t *pixels_claimed, uint64_t *pixels_total, uint32_t *phase);
+
 /* Camera::render on every GPU of rl_init_multi: image row r is rendered by GPU r mod G with the single-GPU
  * kernels (no collective during the render), then ONE exchange — ncclSend / ncclRecv of ceil(H/G)*W*3 f64 per peer to GPU 0 in one
  * RCCL group, each peer over its own xGMI link — and a de-interleave kernel on GPU 0.  The frame is bit-identical for every G.

@@ -162,7 +162,7 @@ def host_lib():
 
 
 # every symbol include/rl_render.h declares (checked by tests/test_abi.py)
-RENDER_SYMBOLS = ["rl_init", "rl_init_multi", "rl_device_count", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info",
+RENDER_SYMBOLS = ["rl_init", "rl_init_multi", "rl_device_count", "rl_shutdown", "rl_last_error", "rl_abi_version", "rl_device_info", "rl_rtiow_render_progress",
                   "rl_scene_destroy", "rl_render_status",
                   "rl_rtiow_scene_create", "rl_bvh_build", "rl_rtiow_render", "rl_rtiow_render_rows", "rl_rtiow_render_device",
                   "rl_rtiow_render_multi", "rl_rtiow_render_multi_device", "rl_rtiow_encode_rgb8_device", "rl_rtiow_render_rgb8",
@@ -243,6 +243,15 @@ def render_status(world, allow_degenerate=False):
     L = render_lib()
     L.rl_debug_slow_traces.restype = C.c_uint64
     return {"rays": st.rays, "flagged": st.flagged, "rc": rc, "slow_traces": L.rl_debug_slow_traces()}
+
+
+def render_progress(world):
+    """rl_rtiow_render_progress: (pixel slots claimed so far in the running launch, slots of that launch, phase) — does not wait for the render."""
+    L = render_lib()
+    a, b, ph = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    L.rl_rtiow_render_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    _check(L.rl_rtiow_render_progress(world.device(), C.byref(a), C.byref(b), C.byref(ph)))
+    return a.value, b.value, ph.value
 
 
 def set_fast_traversal(on):

@@ -276,6 +276,7 @@ static void destroy_one(rl_scene *s) {
   for (hipEvent_t e : s->ev_status)
     if (e) hipEventDestroy(e);
   if (s->ev_last) hipEventDestroy(s->ev_last);
+  if (s->h_progress) hipHostFree(s->h_progress);
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->ev_gather_read) hipEventDestroy(s->ev_gather_read);
@@ -868,7 +869,12 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     int rco = order_after_previous(scene, stream);
     if (rco != RL_OK) return rco;
   }
-  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));
+  HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 512, stream));  // [0] work counter, [64..] stats, [256] cooperative kernel's / stealing counter
+  if (scene->progress_on) {  // the work counter in host-visible memory (rl_rtiow_render_progress)
+    const_cast<rl_scene *>(scene)->progress_total = slots;
+    P.work_counter = scene->d_progress;
+    HIP_TRY(hipMemsetAsync(scene->d_progress, 0, 8, stream));
+  }
   size_t scene_bytes = (size_t)P.n_ops * sizeof(DevOp) + (size_t)P.n_spheres * sizeof(DevSphere);
   auto launch = [&](auto kern, int nt, size_t rng_bytes, bool lds_scene) -> int {
     size_t lds = rng_bytes + (lds_scene ? scene_bytes : 0);
@@ -1109,6 +1115,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
                                      stream);
     if (rc != RL_OK) return rc;
     HIP_TRY(hipMemsetAsync(scene->d_scratch, 0, 4, stream));  // work counter only; stats keep accumulating
+    if (scene->progress_on) P.work_counter = scene->d_progress + 1;  // the resume launch counts in the second host-visible word
     P.sample_begin = lpt_first, P.sample_end = cam->samples_per_pixel, P.resume = 1;
     P.tile_order = ms->d_tile_order, P.tile_cost = nullptr;
     if (variant == 1029 && !want_stats && g_sw.steal_max_fill > 0.0 && (double)npix <= g_sw.steal_max_fill * (double)g_cus * 1024.0) {
@@ -1199,6 +1206,35 @@ int rl_render_status(const rl_scene *scene, rl_stats *st) {
   if (n > 1) rl::use_context(0);
   if (st) *st = acc;
   if (acc.flagged) return set_err(RL_E_DEGENERATE, "a reference panic site was reached (see stats.flagged)");
+  return RL_OK;
+}
+
+int rl_rtiow_render_progress(const rl_scene *scene, uint64_t *pixels_claimed, uint64_t *pixels_total, uint32_t *phase) {
+  if (!g_ready) return set_err(RL_E_NO_DEVICE, "rl_init has not succeeded");
+  if (!scene || scene->kind != 1) return set_err(RL_E_INVALID, "bad argument");
+  rl_scene *ms = const_cast<rl_scene *>(scene);
+  unsigned long long total = 0, c0 = 0, c1 = 0;
+  {
+    std::lock_guard<std::mutex> lk(ms->mu);
+    if (!ms->progress_on) {  // first call: renders enqueued from now on count in host-visible memory
+      if (ms->ctx < 0 || (size_t)ms->ctx >= g_ctx.size()) return set_err(RL_E_INVALID, "scene belongs to a device context that no longer exists");
+      int rc = rl::use_context(ms->ctx);
+      if (rc != RL_OK) return rc;
+      HIP_TRY(hipHostMalloc((void **)&ms->h_progress, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(ms->h_progress, 0, 64);
+      HIP_TRY(hipHostGetDevicePointer((void **)&ms->d_progress, ms->h_progress, 0));
+      ms->progress_on = true;
+    }
+    total = ms->progress_total;
+    c0 = __atomic_load_n(&ms->h_progress[0], __ATOMIC_RELAXED), c1 = __atomic_load_n(&ms->h_progress[1], __ATOMIC_RELAXED);
+  }
+  // lanes that find the queue empty still bump the counter: clamp; the resume launch has started once its counter moves
+  const unsigned ph = c1 != 0 ? 1u : 0u;
+  unsigned long long claimed = ph ? c1 : c0;
+  if (claimed > total) claimed = total;
+  if (pixels_claimed) *pixels_claimed = claimed;
+  if (pixels_total) *pixels_total = total;
+  if (phase) *phase = ph;
   return RL_OK;
 }
 

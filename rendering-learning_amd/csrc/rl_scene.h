@@ -123,6 +123,13 @@ struct rl_scene {
   uint32_t *d_wfg_q0 = nullptr, *d_wfg_q1 = nullptr, *d_wfg_qs = nullptr, *d_wfg_ctl = nullptr;
   size_t wfg_pix_cap = 0, wfg_slot_cap = 0;
   void *h_wfg = nullptr;
+  // rl_rtiow_render_progress (opt-in: its first call switches it on for the renders that follow): the kernels' work counters then live
+  // in two words of pinned HOST memory the device reaches over PCIe — [0] the first (or only) launch of a render, [1] the cost-sorted
+  // resume launch — so that the host reads them with plain loads while the kernels run; `progress_total` = slots of the render enqueued last
+  bool progress_on = false;
+  unsigned long long progress_total = 0;
+  uint32_t *h_progress = nullptr;   // host address
+  uint32_t *d_progress = nullptr;   // the same words as the device sees them
   void *d_params = nullptr;  // device copies (two slots) of the parameter block for the kernels that take it by pointer
   unsigned params_slot = 0;
   uint32_t *d_pix_rays = nullptr;  // debug (tools/): per-pixel ray counts of the last counting render

@@ -60,3 +60,36 @@ def test_concurrent_rtc_renders_of_one_world(rl, golden):
     rl.api.render_status(w)
     torch.cuda.synchronize(dev)
     assert np.array_equal(a.cpu().numpy(), ref1) and np.array_equal(b.cpu().numpy(), ref2)
+
+
+def test_progress_of_a_running_render_can_be_polled(rl):
+    """rl_rtiow_render_progress — the C ABI's form of camera.rs:176-184 ("Scanline-equivalents remaining", once per image_width finished
+    pixels): polled from the host while an asynchronous render runs, it must not wait for the render and must climb to the launch's total."""
+    import time
+
+    import torch
+    dev = torch.device("cuda", 0)
+    world = rl.World.bouncing_spheres(1)
+    assert rl.api.render_progress(world) == (0, 0, 0)  # the first call switches the host-visible work counters on
+    p = rl.CameraParams(**{**world.params.__dict__, "image_width": 1280, "samples_per_pixel": 256, "max_depth": 50})
+    cam = rl.Camera(p)
+    buf = torch.zeros((cam.c.image_height, cam.c.image_width, 3), dtype=torch.float64, device=dev)
+    cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+    seen, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < 20.0:
+        claimed, total, phase = rl.api.render_progress(world)
+        seen.append((claimed, total, phase))
+        if phase == 1 and claimed >= total:
+            break
+        time.sleep(0.001)
+    st = rl.api.render_status(world)
+    gs = {}
+    assert np.array_equal(buf.cpu().numpy(), cam.render(world, stats=gs).data) and st["rays"] == gs["rays"]  # same frame with the counters in host memory
+    tiles = ((cam.c.image_width + 7) // 8) * ((cam.c.image_height + 7) // 8)
+    assert all(t == tiles * 64 for _, t, _ in seen)
+    assert seen[-1][0] == tiles * 64 and seen[-1][2] == 1 and st["rays"] > 0
+    mid = [c for c, t, _ in seen if 0 < c < t]
+    assert mid, seen[:5]  # the poll returned while the kernels were still handing pixels out
+    for ph in (0, 1):  # within a launch the count only grows
+        cs = [c for c, _, q in seen if q == ph]
+        assert cs == sorted(cs)
