@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run frame check (profiling passes)")
     ap.add_argument("--check-rows", type=int, default=8)
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect the headline kernel's rocprofv3 counters in this run (the roofline then uses profiles/valu.json)")
     ap.add_argument("--configs", default="cfg3,cfg4,cfg5", help="non-headline BASELINE configs appended to the line at N = 1 ('' = none)")
     ap.add_argument("--cfg4-spp", type=int, default=512)
     ap.add_argument("--cfg5-spp", type=int, default=256)
@@ -79,8 +81,80 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.run(cmd).returncode)
 
 
-def valu_profile(W, H, spp, depth):
-    """SQ-counter figures of the timed kernel on this workload (profiles/valu.json, written from tools/pmc.sh passes)."""
+def live_valu_profile(args):
+    """The headline kernel's per-ray counter figures MEASURED IN THIS RUN: six rocprofv3 --pmc child passes (counters only) over
+    tools/cfg_workload.py cfg2 — the same scene, frame, sample count and kernel the timed loop below renders — started BEFORE this process
+    touches the GPU (a process that holds the GPU must not spawn programs on this pool).  None when rocprofv3 is missing or a pass fails:
+    the roofline then falls back to profiles/valu.json and says so."""
+    import shutil
+    import tempfile
+    if args.no_live_pmc or args.gpus != 1 or args.inprocess or args.emulate_shard > 1 or os.environ.get("WORLD_SIZE") is not None:
+        return None
+    if args.width != 1920 or args.depth != 50 or shutil.which("rocprofv3") is None:
+        return None
+    # under a profiler already (rocprofv3 -- python3 bench.py): its preloaded library has initialised the GPU in this very process
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        pmc = importlib.import_module("pmc_roofline")
+        t0 = time.perf_counter()
+        out_dir = tempfile.mkdtemp(prefix="rl_bench_pmc_")
+        r = pmc.measure("cfg2", str(args.spp), "headline", out_dir=out_dir, label="bench.py", timeout_s=150, quiet=True)
+        shutil.rmtree(out_dir, ignore_errors=True)
+        need = ("valu_lane_ops_per_ray_f32_weighted", "valu_issue_slots_per_ray", "lanes_active_frac", "lds_array_cycles_per_ray", "valu_wave_insts_per_ray")
+        if r is None or any(r.get(k) is None for k in need):
+            return None
+        w = r["workload"]
+        r.update({"workload_scene": "bouncing_spheres(1)", "width": w["W"], "height": w["H"], "depth": w["depth"], "pmc_spp": w["spp"], "kernel": "rtiow_wave_kernel<1024,4,false>",
+                  "live": True, "live_seconds": time.perf_counter() - t0,
+                  "source": f"MEASURED IN THIS RUN: six rocprofv3 --pmc child passes over tools/cfg_workload.py cfg2 {w['spp']} (tools/pmc_roofline.py `headline` set: "
+                            f"SQ instruction classes, lanes per instruction, LDS, wave-cycle shares, FETCH_SIZE, WRITE_SIZE + L2 hits) before the timed loop, "
+                            f"{time.perf_counter() - t0:.0f} s"})
+        return r
+    except Exception as e:  # noqa: BLE001 — the bench line must not depend on the profiler
+        print(f"[bench] live counter passes failed ({type(e).__name__}: {e}); using profiles/valu.json", file=sys.stderr, flush=True)
+        return None
+
+
+LIVE_CFG = {}  # tag -> per-ray counter figures of a `configs` entry's timed kernel measured in this run (live_cfg_profiles)
+
+
+def live_cfg_profiles(args):
+    """The same for the other BASELINE configs' timed kernels (rtc_kernel, rtiow_fast_general_kernel on cfg 4 / cfg 5), at reduced sample
+    counts (per-ray instruction and byte counts hardly depend on them; `pmc_spp` says which) so that the passes add about 1.5 minutes."""
+    import shutil
+    import tempfile
+    if args.no_live_pmc or not args.configs or shutil.which("rocprofv3") is None or args.gpus != 1 or args.inprocess or args.emulate_shard > 1:
+        return
+    if os.environ.get("WORLD_SIZE") is not None or "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return
+    which = [c.strip() for c in args.configs.split(",") if c.strip()]
+    jobs = ([("cfg3_aa1", "20"), ("cfg3_aa8", "2")] if "cfg3" in which else []) + ([("cfg4", str(min(args.cfg4_spp, 128)))] if "cfg4" in which else []) + \
+           ([("cfg5", str(min(args.cfg5_spp, 64)))] if "cfg5" in which else [])
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        pmc = importlib.import_module("pmc_roofline")
+        for tag, spp in jobs:
+            t0 = time.perf_counter()
+            out_dir = tempfile.mkdtemp(prefix="rl_bench_pmc_")
+            r = pmc.measure(tag, spp, "config", out_dir=out_dir, label="bench.py", timeout_s=150, quiet=True)
+            shutil.rmtree(out_dir, ignore_errors=True)
+            if r is None or r.get("valu_lane_ops_per_ray_f32_weighted") is None:
+                continue
+            base = cfg_profile(tag) or {}
+            r.update({"kernel": base.get("kernel"), "bound": base.get("bound"), "live": True, "pmc_spp": spp,
+                      "source": f"MEASURED IN THIS RUN: rocprofv3 --pmc child passes over tools/cfg_workload.py {tag} {spp} before the timed loop, {time.perf_counter() - t0:.0f} s"})
+            LIVE_CFG[tag] = r
+            print(f"[bench] live counters {tag}: {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] live counter passes for the configs failed ({type(e).__name__}: {e}); using profiles/", file=sys.stderr, flush=True)
+
+
+def valu_profile(W, H, spp, depth, live=None):
+    """SQ-counter figures of the timed kernel on this workload: measured in this run (live_valu_profile) or, failing that, profiles/valu.json."""
+    if live is not None and live.get("width") == W and live.get("depth") == depth and live.get("pmc_spp") == spp:
+        return live
     path = os.path.join(ROOT, "profiles", "valu.json")
     try:
         vj = json.load(open(path))
@@ -101,13 +175,16 @@ def cfg_roofline(tag, rays, kernel_s, alg_bytes):
     """The roofline object of one `configs` entry: this run's rays and kernel time x the per-ray counter figures of profiles/."""
     roof = {"algorithmic_bytes_per_ray": alg_bytes / max(1.0, rays), "algorithmic_gbs": alg_bytes / kernel_s / 1e9,
             "hbm_peak_gbs": 8000.0, "valu_peak_tlaneops": VALU_PEAK_TLANEOPS}
-    pj = cfg_profile(tag)
+    pj = LIVE_CFG.get(tag) or cfg_profile(tag)
     if not pj:
         roof["note"] = f"no profiles/roofline_{tag}.json: counter figures not available"
         return roof
     rps = rays / kernel_s
     roof["kernel"] = pj.get("kernel")
     roof["per_ray_figures_from"] = pj.get("source")
+    roof["counters_measured_in_this_run"] = bool(pj.get("live"))
+    if pj.get("pmc_spp") is not None:
+        roof["pmc_spp"] = pj.get("pmc_spp")
     if pj.get("valu_lane_ops_per_ray_f32_weighted") is not None:
         ach = pj["valu_lane_ops_per_ray_f32_weighted"] * rps / 1e12
         roof.update({"valu_achieved_tlaneops": ach, "valu_frac": ach / VALU_PEAK_TLANEOPS,
@@ -212,7 +289,8 @@ def bench_rtc_config(rl, oracle, np, torch, dev, world, aa, frames, threads, tag
     st = {}
     cbuf = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
     world.render_device(cbuf.data_ptr(), aa, stream=stream.cuda_stream, stats=st)  # counting instantiation (also the warm-up)
-    world.render_device(buf.data_ptr(), aa, stream=stream.cuda_stream)
+    for _ in range(max(1, min(frames, 200))):  # untimed: the GPU has idled through the CPU legs above — bring its clocks back before a 50 ms loop
+        world.render_device(buf.data_ptr(), aa, stream=stream.cuda_stream)
     rl.api.render_status(world)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -265,7 +343,7 @@ def other_configs(args, rl, np, torch, dev):
     res = []
     if "cfg3" in which:
         w = rl.RtcWorld.test_obj_scene(open(os.path.join(G, "teapot-low.obj"), "rb").read(), 1920, 1080)
-        res.append(bench_rtc_config(rl, oracle, np, torch, dev, w, 1, 100, threads, "cfg3_aa1", log))
+        res.append(bench_rtc_config(rl, oracle, np, torch, dev, w, 1, 200, threads, "cfg3_aa1", log))
         res.append(bench_rtc_config(rl, oracle, np, torch, dev, w, 8, 5, threads, "cfg3_aa8", log))
         del w
     if "cfg4" in which or "cfg5" in which:
@@ -303,6 +381,9 @@ def main():
     if ws_env is None and args.gpus > 1 and not args.inprocess:
         spawn_ranks(args)
     world_size = int(ws_env) if ws_env is not None else 1
+    live = live_valu_profile(args)  # (child processes: before anything here touches the GPU)
+    if world_size == 1:
+        live_cfg_profiles(args)
     if args.inprocess:
         if world_size != 1:
             raise SystemExit("--inprocess is a single-process mode: do not start it under a launcher")
@@ -459,7 +540,7 @@ def main():
         launches = 2 if (args.spp >= 64 and os.environ.get("RL_LPT", "1") != "0") else 1
         # SURVEY.md §8d's algorithmic bytes (what a scene-from-HBM traversal would move): reported, NOT the bound
         alg_bytes = 64.0 * st["node_tests"] + 64.0 * st["sphere_tests"] + 208.0 * st["rays"]
-        vp = valu_profile(W, H, args.spp, args.depth)
+        vp = valu_profile(W, H, args.spp, args.depth, live)
         roof = {"bound": "valu", "unit": "Tlane-op/s", "peak": VALU_PEAK_TLANEOPS, "kernel": vp["kernel"] if vp else "rtiow_wave_kernel<1024,4,false>",
                 "kernel_ms": kernel_ms, "kernel_ms_max_rank": kernel_ms_max, "launches_per_step": launches, "kernel_avg_launch_ms": kernel_ms / launches,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gbs": alg_bytes / k_s / 1e9, "traffic": None}
@@ -479,11 +560,12 @@ def main():
                          "traffic": (vp["hbm_bytes_per_ray"] * rank_rays / launches) if vp.get("hbm_bytes_per_ray") is not None else vp.get("hbm_bytes_per_launch"),
                          "hbm_gbs": (vp["hbm_bytes_per_ray"] * rank_rays / k_s / 1e9) if vp.get("hbm_bytes_per_ray") is not None else None,
                          "hbm_frac_of_8TBs": (vp["hbm_bytes_per_ray"] * rank_rays / k_s / 8e12) if vp.get("hbm_bytes_per_ray") is not None else None,
-                         "l2_hit_rate": vp.get("l2_hit_rate"), "pmc_spp": vp.get("pmc_spp"),
+                         "l2_hit_rate": vp.get("l2_hit_rate"), "pmc_spp": vp.get("pmc_spp"), "counters_measured_in_this_run": bool(vp.get("live")),
+                         "wave_cycle_shares": vp.get("wave_cycle_shares"),
                          "per_ray_figures_from": vp.get("source"),
                          "note": ("per-ray instruction counts are rocprofv3 SQ counters of this kernel on this workload" +
                                   ("" if vp.get("pmc_spp") == args.spp else f" at {vp.get('pmc_spp')} spp (this run: {args.spp}: the 8-sample probe launch has another share of the frame)") +
-                                  " (profiles/, not collected in this run); ") +
+                                  (", collected by child passes of this run before the timed loop; " if vp.get("live") else " (profiles/, not collected in this run); ")) +
                                  "rays and kernel time are this run's. frac = valu_issue_frac x lanes_active_frac at the nominal 2.4 GHz; the scene is LDS / L2-resident, "
                                  "HBM traffic is the framebuffer"})
         else:
