@@ -22,8 +22,12 @@ Prints ONE JSON line (rank 0). Extra objects:
                  binary64 instructions weighted 2x (they hold the pipe twice as long); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
                  frac = valu_issue_frac (share of the SIMDs' issue slots used) x lanes_active_frac (lanes doing work per
                  instruction).  lds_frac = LDS-array busy cycles / CU cycles.
-                 `traffic` = measured HBM bytes per launch (profiles/), algorithmic_bytes = SURVEY.md §8d's figure, both reported,
-                 neither the bound.
+                 `traffic` = measured HBM bytes per launch, algorithmic_bytes = SURVEY.md §8d's figure, both reported, neither the bound.
+                 The counter figures are MEASURED IN THE RUN: before this process touches the GPU it starts rocprofv3 --pmc child passes
+                 (counters only, tools/pmc_roofline.py) over tools/cfg_workload.py = the same scene / frame / sample count / kernel
+                 (`counters_measured_in_this_run`; --no-live-pmc or a missing profiler fall back to profiles/valu.json / roofline_cfg*.json).
+  configs      — BASELINE configs[2..4] at their stated sizes after the headline loop (N = 1): each with its own check, roofline figures
+                 (counter passes at reduced sample counts, `pmc_spp`) and CPU sample.
   check        — after the timed loop: the timed frame equals the counting kernel's frame bit for bit; 8 full-spp rows of the real
                  frame are re-rendered by the CPU oracle (counters exact, max |err| of the pixel means).
   cpu_baseline — the CPU oracle (C++ restatement of the reference; the Rust reference cannot be built here) timed on this
