@@ -231,6 +231,7 @@ void to_world(const rl_rtiow_scene_desc &d, const std::vector<DevOp> &ops, const
 }
 
 struct GItem {
+  uint32_t seg = 0;  // segment of the program the occurrence belongs to (FastGeneral::seg_roots)
   FastItem it;
   Box box;       // world-space bounds (unpadded)
   double r = 0;  // spheres: radius; else 0
@@ -275,7 +276,6 @@ void set_build_octo(bool on) { g_build_octo = on; }
 
 bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, FastGeneral &out) {
   out = FastGeneral{};
-  if (rt.has_media) return false;  // a ConstantMedium draws from the RNG while the world is traversed: the reference's order is part of its result
   const std::vector<DevOp> &ops = rt.ops;
   // ---- matrices: finite, bounded norm (an instance normal M^-T n of a unit n then has |.|^2 >= 1 / (3 |M|_inf^2) >> 1e-16)
   for (uint32_t i = 0; i < d.n_transforms; i++) {
@@ -290,6 +290,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   // ---- items = primitive occurrences, in program order
   std::vector<GItem> items;
   std::vector<uint32_t> pushes;
+  uint32_t cur_seg = 0;  // media seen so far = the segment the next primitive occurrence belongs to
   auto chain_of = [&](GItem &g) {
     g.it.chain = pushes.empty() ? NONE : pushes.back();
     double ninv = 1.0, shift = 0.0;
@@ -318,7 +319,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     double r = std::fabs(sp.radius);
     if (!(std::isfinite(sp.radius) && r > 0.0)) return false;
     GItem g;
-    g.it.kind = 0, g.it.payload = payload, g.it.op_pc = pc;
+    g.it.kind = 0, g.it.payload = payload, g.it.op_pc = pc, g.seg = cur_seg;
     chain_of(g);
     double lo[3], hi[3], cmax = 0.0;
     for (int ax = 0; ax < 3; ax++) {
@@ -339,7 +340,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     const rl_planar &pl = d.planars[idx];
     if (pl.kind != RL_PLANAR_QUAD && pl.kind != RL_PLANAR_TRIANGLE) return false;  // an unbounded Plane has no box
     GItem g;
-    g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc;
+    g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc, g.seg = cur_seg;
     chain_of(g);
     double pts[4][3];
     for (int ax = 0; ax < 3; ax++) {
@@ -366,6 +367,13 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     const DevOp &op = ops[pc];
     uint32_t kind = op.code & 0xFFu;
     bool ok = true;
+    if (kind == OP_MEDIUM_BEGIN) {  // the boundary's own ops (up to the matching END) are not world primitives: the medium evaluates them itself
+      out.media.push_back(FastMedium{pc, pushes.empty() ? NONE : pushes.back()});
+      cur_seg++;
+      if (op.skip == 0 || op.skip > ops.size()) return false;
+      pc = op.skip - 1;  // the OP_MEDIUM_END; the loop continues behind it
+      continue;
+    }
     if (kind == OP_PUSH_TRANSLATE || kind == OP_PUSH_TRANSFORM) pushes.push_back(pc);
     else if (kind == OP_POP_TRANSLATE || kind == OP_POP_TRANSFORM) pushes.pop_back();
     else if (kind == OP_SPHERE) ok = add_sphere(op.a, pc);
@@ -375,9 +383,11 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     if (!ok) return false;
   }
   const size_t n = items.size();
-  if (n >= 0x7FFFFFF0u) return false;
+  if (n >= 0x3FFFFFF0u || out.media.size() >= 0x10000u) return false;
+  const size_t n_seg = out.media.size() + 1;
   if (n == 0) {
     out.ok = true, out.root = NONE, out.r_safe = 1e30f;
+    out.seg_roots.assign(n_seg, NONE);
     return true;
   }
   for (const GItem &g : items)
@@ -538,11 +548,23 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     ob.grow(bb);
     return self;
   };
-  if (n == 1) out.root = FASTG_LEAF | 0u;  // a single occurrence: rays start in LEAF, no node at all
-  else {
-    Box all;
-    out.root = build(0, n, FASTG_MAX_DEPTH, all);
+  // one tree per segment (items are in program order, so a segment is a contiguous range of ids)
+  std::vector<uint32_t> broots(n_seg, NONE);
+  {
+    size_t lo = 0;
+    for (size_t sg = 0; sg < n_seg; sg++) {
+      size_t hi = lo;
+      while (hi < n && items[hi].seg == sg) hi++;
+      if (hi - lo == 1) broots[sg] = FASTG_LEAF | (uint32_t)lo;  // a single occurrence: rays start in LEAF, no node at all
+      else if (hi > lo) {
+        Box all;
+        broots[sg] = build(lo, hi, FASTG_MAX_DEPTH, all);
+      }
+      lo = hi;
+    }
+    if (lo != n) return false;
   }
+  out.root = broots[0];
   // rays from outside r_safe: guard_pad's bound 8 (8u L^2 + 2u M L) / r with L = |oc| <= distance + radius and M <= L + |centre|, for the
   // smallest sphere; planars need far less (a relative 1e-15 of the coordinates), so one constant serves all items
   {
@@ -557,8 +579,8 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   }
   // ---- four-wide form: fold every second level (the child with the largest box is replaced by its own two children until four are held)
   out.qnodes.clear();
-  out.qroot = out.root;
-  if (out.root != NONE && !(out.root & FASTG_LEAF)) {
+  out.seg_roots = broots;
+  {
     struct Cand {
       float box[6];
       uint32_t e;
@@ -600,14 +622,16 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
       }
       return self;
     };
-    out.qroot = fold(out.root);
+    for (size_t sg = 0; sg < n_seg; sg++)
+      if (broots[sg] != NONE && !(broots[sg] & FASTG_LEAF)) out.seg_roots[sg] = fold(broots[sg]);
   }
+  out.qroot = out.seg_roots[0];
   // ---- eight-wide form with quantised boxes (FastNodeO): fold until eight children are held (largest box first), then put every child's
   // box on the node's 8-bit grid, rounded OUTWARDS — checked below in exact arithmetic (every term is a dyadic rational that binary64 holds)
   out.onodes.clear();
   out.oroot = out.root;
   bool octo_ok = true;
-  if (g_build_octo && out.root != NONE && !(out.root & FASTG_LEAF)) {
+  if (g_build_octo && n_seg == 1 && out.root != NONE && !(out.root & FASTG_LEAF)) {
     struct Cand {
       float box[6];
       uint32_t e;

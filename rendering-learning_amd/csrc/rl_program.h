@@ -169,6 +169,15 @@ struct alignas(16) FastItem {
   uint32_t chain;    // pc of the innermost PUSH op around the primitive (NONE: world space); ops[pc].b = the next one outwards
   uint32_t op_pc;    // the op that holds the primitive in the reference's program
 };
+// A ConstantMedium of the scene as the fast traversal sees it (round 3): the reference evaluates it where its fold reaches it — after
+// every primitive that precedes it in the threaded program — with ray_t.max = the closest hit found so far (constant_medium.rs:27-80).
+// The items are therefore cut into SEGMENTS at the media (segment s = the primitive occurrences between medium s - 1 and medium s in
+// program order), each segment has its own tree, and a ray walks tree 0, evaluates medium 0, walks tree 1, ... (rl_rtiow_fastgen.h MEDIA).
+static const uint32_t FASTG_MEDIUM = 0x40000000u;  // entry / `best`: a medium (low bits: its index in FastGeneral::media)
+struct FastMedium {
+  uint32_t pc;     // its OP_MEDIUM_BEGIN
+  uint32_t chain;  // pc of the innermost PUSH op around it (NONE: world space)
+};
 struct FastGeneral {
   std::vector<FastNodeG> nodes;
   std::vector<FastNodeQ> qnodes;  // four-wide form of `nodes` (collapse_fast_general)
@@ -178,7 +187,9 @@ struct FastGeneral {
   std::vector<DevSphere> item_spheres;  // [item]: the sphere record of a sphere item (zero for planars), so that LEAF fetches item and sphere side by side
   std::vector<uint32_t> item_material;  // [item]: material index of the primitive
   uint32_t root = NONE;      // entry a new ray starts at (NONE: nothing to hit)
-  uint32_t qroot = NONE;     // ... in the four-wide form
+  uint32_t qroot = NONE;     // ... in the four-wide form (= seg_roots[0])
+  std::vector<uint32_t> seg_roots;  // four-wide root entry of every segment (one segment, no media: {qroot})
+  std::vector<FastMedium> media;    // seg_roots.size() == media.size() + 1
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
   float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)
   float radius = 0, pad_k = 0;  // ... box growth for those rays = pad_k * (distance to centre + radius)^2 (world units)

@@ -265,7 +265,7 @@ static void destroy_one(rl_scene *s) {
   hipFree(s->d_transforms), hipFree(s->d_materials), hipFree(s->d_textures), hipFree(s->d_images), hipFree(s->d_image_pool), hipFree(s->d_perlins), hipFree(s->d_media);
   hipFree(s->d_tris), hipFree(s->d_xforms), hipFree(s->d_rmaterials), hipFree(s->d_lights), hipFree(s->d_scratch);
   hipFree(s->d_pos), hipFree(s->d_tile_cost), hipFree(s->d_tile_order), hipFree(s->d_tile_keys), hipFree(s->d_tile_iota), hipFree(s->d_sort_temp);
-  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_steal_state), hipFree(s->d_steal_n), hipFree(s->d_fg_nodes), hipFree(s->d_fg_onodes), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
+  hipFree(s->d_shapes), hipFree(s->d_csgs), hipFree(s->d_patterns), hipFree(s->d_guards), hipFree(s->d_shard), hipFree(s->d_pix_rays), hipFree(s->d_fast_nodes), hipFree(s->d_fast_leaf_boxes), hipFree(s->d_coop_pixels), hipFree(s->d_steal_state), hipFree(s->d_steal_n), hipFree(s->d_fg_nodes), hipFree(s->d_fg_onodes), hipFree(s->d_fg_seg_roots), hipFree(s->d_fg_media), hipFree(s->d_fg_items), hipFree(s->d_fg_spheres), hipFree(s->d_fg_material);
 #ifdef RL_EXPERIMENTAL
   if (ExpBuffers *E = (ExpBuffers *)s->exp) {
     hipFree(E->wf_pix), hipFree(E->wf_ray), hipFree(E->wf_hit), hipFree(E->wf_qtrav), hipFree(E->wf_qshade), hipFree(E->wf_qgen), hipFree(E->wf_ctl);
@@ -486,7 +486,8 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && ((rc = upload(H->fast_nodes, &s->d_fast_nodes)) || (rc = upload(H->fast_leaf_boxes, &s->d_fast_leaf_boxes)))) ||
-      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.onodes, &s->d_fg_onodes)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
+      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.onodes, &s->d_fg_onodes)) || (rc = upload(H->fg.seg_roots, &s->d_fg_seg_roots)) ||
+                    (rc = upload(H->fg.media, &s->d_fg_media)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
     destroy_one(s);
     return nullptr;
   }
@@ -753,6 +754,7 @@ static int fill_rtiow_params(const rl_scene *scene, const rl_rtiow_camera *cam, 
 #ifdef RL_EXPERIMENTAL
   P.fg_onodes = scene->d_fg_onodes, P.fg_oroot = H.fg.oroot;
 #endif
+  P.fg_seg_roots = scene->d_fg_seg_roots, P.fg_media = scene->d_fg_media, P.fg_n_seg = (uint32_t)H.fg.seg_roots.size();
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;
@@ -791,9 +793,10 @@ static int choose_rtiow_variant(const rl_scene *scene, const rl_rtiow_camera *ca
   // pool / wave2 / wavefront) is A/B material and lives in librl_render_exp.so (make exp).
   int variant = g_sw.rtiow_variant;
   const bool general = rt.has_planars || rt.has_instances || rt.has_images || rt.has_noise || rt.has_media;
-  // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG while the world is traversed: the reference-order kernels evaluate it (the
-  // wave-scheduled one as a scope of the threaded program, the nested-loop one by recursion: RL_RTIOW_KERNEL=general); no fast traversal
-  if (rt.has_media && variant != 2) variant = 4;
+  // a ConstantMedium (RL_H_MEDIUM) draws from the pixel's RNG where the reference's fold reaches it: the reference-order kernels evaluate
+  // it as a scope of the threaded program (wave-scheduled) or by recursion (RL_RTIOW_KERNEL=general); the fast traversal walks one tree per
+  // program segment between two media (rl_rtiow_fastgen.h MEDIA) — counter-free renders only, as for every fast traversal
+  if (rt.has_media && variant != 2 && variant != 0 && variant != 1031) variant = 4;
 #ifndef RL_EXPERIMENTAL
   if (variant == 1 || variant == 3 || variant == 5 || variant == 6 || variant == 7 || variant == 256 || variant == 512 || variant == 768 || variant == 1035)
     return set_err(RL_E_UNSUPPORTED, "this kernel variant is A/B material and lives in librl_render_exp.so only (make -C rendering-learning_amd/csrc exp)");
@@ -805,7 +808,7 @@ static int choose_rtiow_variant(const rl_scene *scene, const rl_rtiow_camera *ca
     // 1035 = the same traversal in WAVEFRONT form (experimental/rl_rtiow_wfg.h): measured, slower, experimental library only
     bool wf = false;
 #ifdef RL_EXPERIMENTAL
-    wf = (variant == 1035 || (variant == 0 && g_sw.wavefront == 1)) && (uint64_t)nrows * W < 0xFFFF0000ull;
+    wf = (variant == 1035 || (variant == 0 && g_sw.wavefront == 1)) && (uint64_t)nrows * W < 0xFFFF0000ull && !rt.has_media;
 #endif
     variant = wf ? 1035 : 1031;
   }
@@ -967,7 +970,11 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
       if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
+      if (rt.has_media) {  // segments + media (the boundary walks and the Isotropic phase function need the 256-register budget)
+        constexpr int NT = 512, SD = 40;
+        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        rc = trans ? launch_ptr(rtiow_fast_general_kernel<NT, SD, true, false, true>, NT, rb) : launch_ptr(rtiow_fast_general_kernel<NT, SD, false, false, true>, NT, rb);
+      } else if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
         constexpr int NT = 512, SD = 40;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
         rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, true>, NT, rb);
@@ -1264,7 +1271,8 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
       unsigned depth;
     };
     std::vector<Frame> st;
-    if (fg.qroot != NONE) st.push_back(Frame{fg.qroot, {0, 0, 0, 0, 0, 0}, false, 1u});
+    for (uint32_t sr : fg.seg_roots)
+      if (sr != NONE) st.push_back(Frame{sr, {0, 0, 0, 0, 0, 0}, false, 1u});
     auto inside = [](const float *outer, const double *lo, const double *hi) {
       for (int ax = 0; ax < 3; ax++)
         if (!((double)outer[2 * ax] <= lo[ax] && hi[ax] <= (double)outer[2 * ax + 1])) return false;

@@ -164,7 +164,15 @@ __device__ __forceinline__ void fastg_sphere_hit(const DevSphere &s, uint32_t pa
 // entry, so that pop() can skip entries that have fallen behind the closest hit (cfg 4 -10 %, cfg 5 -6 %: the skipped visits are worth less
 // than the dependent LDS round trips of the skipping loop).
 // OCTO: the eight-wide nodes with quantised boxes (FastNodeO) instead of the four-wide ones (FastNodeQ)
-template <int NT, int SD, bool TRANS, bool OCTO = false>
+// MEDIA (round 3): scenes with ConstantMedium objects (constant_medium.rs:27-80, deterministic variant: include/rl_render.h rl_medium).  The
+// reference evaluates a medium where its fold reaches it, with ray_t.max = the closest hit found by everything BEFORE it in the program,
+// and draws the free path from the RNG only if the ray's stretch inside the boundary, clamped to that closest hit, is non-empty.  So the
+// items are cut into segments at the media (FastGeneral::seg_roots): a ray walks segment 0's tree, evaluates medium 0 with the closest hit
+// so far (the boundary by the reference's own fold over its ops, twice; the draw from the pixel's ChaCha8 ring), walks segment 1's tree
+// with the same running closest hit, ... — exactly the reference's order at the granularity that matters.  (BVH boxes around a medium
+// never decide whether it draws: a ray that misses a box inside [t_min, closest] has an empty stretch inside the boundary, too.)  An
+// order-sensitive ray rewinds the ring to the word position the ray started at and is re-traced by the reference's fold WITH its media.
+template <int NT, int SD, bool TRANS, bool OCTO = false, bool MEDIA = false>
 __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParams *__restrict__ Pp) {
   // the parameter block is read from memory where it is needed (uniform addresses: scalar loads through the constant cache) instead of
   // arriving by value: by value every field that is live anywhere is loaded at kernel entry and pins SGPRs for the kernel's life time
@@ -195,6 +203,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
   double time = 0.0, closest = INF;
   uint32_t pc = 0, best = NONE, depth = 0, sp = 0, steps = 0;
   const uint32_t step_budget = P.tune[3];
+  uint32_t seg = 0, pos0 = 0, ray_flags = 0;  // MEDIA: segment being walked, ChaCha word position at the start of the ray, panic sites of its boundary walks
   bool amb = false;
   // rays that start farther than r_safe from the scene's centre (e.g. inside a huge ground sphere): the boxes' padding was sized for
   // origins inside r_safe, so such a ray widens every box interval by `grow` and does NOT prune by the closest hit — every sphere its
@@ -208,12 +217,18 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
 
   auto go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), an item (LEAF), or nothing left (SHADE)
     if (++steps > step_budget) amb = true, e = NONE;
+    if (MEDIA && e == NONE && !amb && seg + 1u < P.fg_n_seg) {  // this segment is done: the medium behind it (LEAF evaluates it), then the next one
+      pc = FASTG_LEAF | FASTG_MEDIUM | seg;
+      state = ST_LEAF;
+      return;
+    }
     if (e == NONE) {
 #ifdef RL_FASTG_VERIFY
       if (false) {
 #else
       if (!amb && best == NONE) {  // a miss needs no SHADE visit: background (camera.rs:257), sample done
 #endif
+        if (MEDIA) c_flag += ray_flags;
         sum = sum + thr * ld3(cam.background);
         n++;
         state = ST_GEN;
@@ -230,6 +245,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
   };
   auto start_ray = [&]() {
     closest = INF, best = NONE, sp = 0, steps = 0;
+    if (MEDIA) seg = 0, pos0 = rng.pos, ray_flags = 0;
     ra32 = ray_aux32_direct(wo, wd);
     float fx = (float)wo.x - P.fg_center[0], fy = (float)wo.y - P.fg_center[1], fz = (float)wo.z - P.fg_center[2];
     float far2 = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
@@ -245,9 +261,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
       if (!(grow < FINF)) amb = true;
     }
 #ifdef RL_EXPERIMENTAL
-    go(amb ? NONE : (OCTO ? P.fg_oroot : P.fg_root));
+    go(amb ? NONE : (MEDIA ? P.fg_seg_roots[0] : OCTO ? P.fg_oroot : P.fg_root));
 #else
-    go(amb ? NONE : P.fg_root);
+    go(amb ? NONE : (MEDIA ? P.fg_seg_roots[0] : P.fg_root));
 #endif
   };
 
@@ -410,6 +426,38 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
 #ifdef RL_FASTG_VERIFY
         c_leaves++;
 #endif
+        if (MEDIA && (pc & FASTG_MEDIUM)) {  // ConstantMedium::hit (constant_medium.rs:27-80) with ray_t = [1e-10, closest so far]
+          const uint32_t k = pc & 0xFFFFu;
+          const FastMedium fm = P.fg_media[k];
+          const DevOp &mop = ops[fm.pc];
+          const rl_medium &m = P.media[mop.a];
+          D3 o, d;
+          replay_chain(P, ops, fm.chain, wo, wd, o, d);
+          Rec r1, r2;
+          r1.t = INF, r1.any = false, r1.pc = 0, r2.t = INF, r2.any = false, r2.pc = 0;
+          GenCounters gc{0, 0, 0, 0, 0};
+          auto nodraw = []() { return 0.0; };
+          general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, o, d, wo, wd, time, -INF, r1, gc, nodraw);  // boundary.hit(r, universe)
+          if (r1.any) general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, o, d, wo, wd, time, r1.t + 1e-4, r2, gc, nodraw);
+          ray_flags += (uint32_t)gc.flagged;
+          if (r1.any && r2.any) {
+            double t1 = fmax(r1.t, 1e-10), t2 = fmin(r2.t, closest);
+            if (!(t1 >= t2)) {
+              t1 = fmax(t1, 0.0);
+              const double ray_length = sqrt(len2(d));
+              const double distance_inside_boundary = (t2 - t1) * ray_length;
+              const double hit_distance = m.neg_inv_density * log(rng.gen_f64());  // the draw, where the reference's fold makes it
+              if (!(hit_distance > distance_inside_boundary)) {
+                const double t = t1 + hit_distance / ray_length;
+                // (a scatter point within the tie band of the hit it replaces: the reference's comparison chain decides)
+                if (best != NONE && fabs(t - closest) <= fast_tie_band(fabs(t) + fabs(closest), ra32.oimax())) amb = true;
+                closest = t, best = FASTG_MEDIUM | k;
+              }
+            }
+          }
+          seg++;
+          go(P.fg_seg_roots[seg]);
+        } else {
         const uint32_t item = pc & ~FASTG_LEAF;
         const FastItem it = items[item];
         const DevSphere isph = P.fg_spheres[item];  // fetched side by side with the item (one round trip, not two)
@@ -424,6 +472,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
         if (it.kind == 0) fastg_sphere_hit(isph, it.payload, o, d, time, oimax, item, closest, best, amb);
         else fastg_planar_hit(P.planars[it.payload], o, d, oimax, item, closest, best, amb);
         go(pop());
+        }
       }
     } else if (pick == ST_FILL) {
       if (state == ST_FILL) {
@@ -505,10 +554,43 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
         Rec rec;
         rec.t = INF, rec.any = false, rec.pc = 0, rec.mat = 0, rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false, rec.front = true;
         rec.p = d3(0.0, 0.0, 0.0), rec.normal = d3(0.0, 0.0, 0.0);
-        if (amb) {  // rare: the answer may depend on the visiting order -> the reference's own fold
-          c_flag += general_slow_trace<TRANS>(P, ops, wo, wd, time, rec);
+        auto slow_trace = [&]() {  // the reference's own fold over the whole program
+          if (MEDIA) {  // ... media included: the ring goes back to where this ray started, and the fold draws as the reference does
+            rng.pos = pos0, rng.blk_lo = pos0 >> 4, rng.nres = 1;
+            rng.gen_block(rng.blk_lo);
+            GenCounters gc{0, 0, 0, 0, 0};
+            auto draw = [&]() { return rng.gen_f64(); };
+            general_trace<false, true>(P, ops, 0u, NONE, wo, wd, wo, wd, time, 1e-10, rec, gc, draw);
+            c_flag += (uint32_t)gc.flagged;
+          } else c_flag += general_slow_trace<TRANS>(P, ops, wo, wd, time, rec);
           c_slow++;
+        };
+        if (amb) {  // rare: the answer may depend on the visiting order -> the reference's own fold
+          slow_trace();
+        } else if (MEDIA && best != NONE && (best & FASTG_MEDIUM)) {  // scattered inside a medium: the record of constant_medium.rs:69-78
+          c_flag += ray_flags;
+          const FastMedium fm = P.fg_media[best & 0xFFFFu];
+          D3 o, d;
+          replay_chain(P, ops, fm.chain, wo, wd, o, d);
+          rec.t = closest, rec.p = o + d * closest, rec.normal = d3(1.0, 0.0, 0.0), rec.u = 0.0, rec.v = 0.0, rec.w = 0.0, rec.uv3 = false;
+          rec.front = true, rec.mat = P.media[ops[fm.pc].a].material, rec.pc = fm.pc, rec.any = true;
+          uint32_t push_pc = fm.chain;  // the POP chain, innermost first (transform.rs:152-161, translate.rs:18)
+#pragma unroll 1
+          while (push_pc != NONE) {
+            const DevOp &op = ops[push_pc];
+            if ((op.code & 0xFFu) == OP_PUSH_TRANSLATE) rec.p = rec.p + ld3(P.translates[op.a].offset);
+            else {
+              const rl_transform &t = P.transforms[op.a];
+              rec.p = mat3_mul(t.m, rec.p);
+              D3 wn = mat3_mul(t.inv_t, rec.normal);
+              double mm = len2(wn);
+              if (approx_eq_eps(mm, 0.0, 1e-16)) c_flag++;
+              else rec.normal = normalize(wn);
+            }
+            push_pc = op.b;
+          }
         } else if (best != NONE) {
+          if (MEDIA) c_flag += ray_flags;
           bool push_skip = false;
           // the HitRecord of the winner: the same test once more with ray_t.max = its root (same arithmetic -> same root), then the
           // POP chain innermost first, as the reference's recursion unwinds (transform.rs:152-161, translate.rs:18)
@@ -537,8 +619,8 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
           } else planar_hit_rec(P.planars[it.payload], it.op_pc, o, d, rec);
           if (sensitive) {  // rare: grazing or next to an axis pole -> the reference's own fold decides
             rec.t = INF, rec.any = false;
-            c_flag += general_slow_trace<TRANS>(P, ops, wo, wd, time, rec);
-            c_slow++;
+            if (MEDIA) c_flag -= ray_flags;  // (the fold counts the boundary walks' panic sites itself)
+            slow_trace();
             push_skip = true;
           }
           uint32_t push_pc = push_skip ? NONE : it.chain;  // (the slow trace returns a world-space record)
@@ -581,14 +663,17 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
         } else {
           const DevMaterial &m = P.materials[rec.mat];
           D3 texc = d3(0.0, 0.0, 0.0);
-          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT) {
+          if (m.kind == RL_MAT_LAMBERTIAN || m.kind == RL_MAT_DIFFUSE_LIGHT || (MEDIA && m.kind == RL_MAT_ISOTROPIC)) {
             double tu, tv;
             rec_uv<TRANS>(rec, tu, tv);
             texc = texture_value<(TRANS ? 2 : 1)>(P, m.texture, tu, tv, rec.p);
           }
           uint32_t kind = m.kind;
           D3 normal = rec.normal;
-          if (kind == RL_MAT_LAMBERTIAN) {
+          if (MEDIA && kind == RL_MAT_ISOTROPIC) {  // material.rs:201-214: Vec3::random_unit_vector, attenuation = texture.value(uv, p)
+            nd = rng.unit_sphere();
+            thr = thr * texc;
+          } else if (kind == RL_MAT_LAMBERTIAN) {
             D3 dir = normal + rng.unit_sphere();
             bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
             nd = near_zero ? normal : dir;

@@ -68,6 +68,10 @@ struct RtiowParams {
   const float *coop_leaf_boxes;        // fast wave kernel, resume launch (A/B): a wave holding a pixel of the first prio_tiles tiles runs at s_setprio 3
   uint32_t *pix_rays;         // debug (tools/): per-pixel ray counts, accumulated at pixel end by the counting wave kernel, or null
   unsigned long long *stats;  // [0]=rays [1]=node_tests [2]=sphere_tests [3]=planar [4]=instance [5]=rng_words [6]=flagged
+  // (appended last: the by-value kernels' kernarg offsets of everything above stay where they were)
+  const uint32_t *fg_seg_roots;  // rl_rtiow_fastgen.h MEDIA: root entry of every program segment (FastGeneral::seg_roots)
+  const FastMedium *fg_media;    // ... and the media between them
+  uint32_t fg_n_seg;
 };
 
 // ---------------------------------------------------------------- ChaCha8

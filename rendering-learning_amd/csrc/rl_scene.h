@@ -64,6 +64,8 @@ struct rl_scene {
   size_t steal_pix = 0;
   rl::FastNodeQ *d_fg_nodes = nullptr;
   rl::FastNodeO *d_fg_onodes = nullptr;
+  uint32_t *d_fg_seg_roots = nullptr;
+  rl::FastMedium *d_fg_media = nullptr;
   rl::FastItem *d_fg_items = nullptr;
   rl::DevSphere *d_fg_spheres = nullptr;
   uint32_t *d_fg_material = nullptr;

@@ -71,7 +71,10 @@ def test_instanced_twice_counts_occurrences_not_primitives(rl):
 
 def test_scenes_that_must_stay_on_the_reference_order_kernels(rl):
     assert _check(rl, rl.World.example_scene("flat_world"))["flags"] == 0     # an unbounded Plane has no box
-    assert _check(rl, rl.World.example_scene("cornell_smoke"))["flags"] == 0  # constant media draw in the reference's order
+    # constant media (round 3): the items are cut into program segments at the media — the six Cornell quads come before both smoke boxes,
+    # whose own boundary quads are not world primitives — and every segment's tree is checked like the single one of a scene without media
+    smoke = _check(rl, rl.World.example_scene("cornell_smoke"))
+    assert smoke["flags"] == 2 and smoke["items"] == 6 and smoke["leaves"] == 6 and smoke["dups"] == 0 and smoke["missing"] == 0 and smoke["box_violations"] == 0
     assert _check(rl, rl.World.example_scene("checkered_spheres"))["flags"] == 1
 
     def vanishing(b):  # a smooth triangle whose interpolated normal passes through zero
