@@ -232,6 +232,7 @@ void to_world(const rl_rtiow_scene_desc &d, const std::vector<DevOp> &ops, const
 
 struct GItem {
   uint32_t seg = 0;  // segment of the program the occurrence belongs to (FastGeneral::seg_roots)
+  int medium = -1;   // >= 0: not a world item but part of that medium's boundary (only its padded box is used: FastGeneral::stage_roots)
   FastItem it;
   Box box;       // world-space bounds (unpadded)
   double r = 0;  // spheres: radius; else 0
@@ -291,6 +292,8 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   std::vector<GItem> items;
   std::vector<uint32_t> pushes;
   uint32_t cur_seg = 0;  // media seen so far = the segment the next primitive occurrence belongs to
+  int in_medium = -1;    // inside the boundary ops of this medium
+  uint32_t medium_end = 0;
   auto chain_of = [&](GItem &g) {
     g.it.chain = pushes.empty() ? NONE : pushes.back();
     double ninv = 1.0, shift = 0.0;
@@ -319,7 +322,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     double r = std::fabs(sp.radius);
     if (!(std::isfinite(sp.radius) && r > 0.0)) return false;
     GItem g;
-    g.it.kind = 0, g.it.payload = payload, g.it.op_pc = pc, g.seg = cur_seg;
+    g.it.kind = 0, g.it.payload = payload, g.it.op_pc = pc, g.seg = cur_seg, g.medium = in_medium;
     chain_of(g);
     double lo[3], hi[3], cmax = 0.0;
     for (int ax = 0; ax < 3; ax++) {
@@ -340,7 +343,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     const rl_planar &pl = d.planars[idx];
     if (pl.kind != RL_PLANAR_QUAD && pl.kind != RL_PLANAR_TRIANGLE) return false;  // an unbounded Plane has no box
     GItem g;
-    g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc, g.seg = cur_seg;
+    g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc, g.seg = cur_seg, g.medium = in_medium;
     chain_of(g);
     double pts[4][3];
     for (int ax = 0; ax < 3; ax++) {
@@ -367,11 +370,34 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     const DevOp &op = ops[pc];
     uint32_t kind = op.code & 0xFFu;
     bool ok = true;
-    if (kind == OP_MEDIUM_BEGIN) {  // the boundary's own ops (up to the matching END) are not world primitives: the medium evaluates them itself
-      out.media.push_back(FastMedium{pc, pushes.empty() ? NONE : pushes.back()});
-      cur_seg++;
-      if (op.skip == 0 || op.skip > ops.size()) return false;
-      pc = op.skip - 1;  // the OP_MEDIUM_END; the loop continues behind it
+    if (kind == OP_MEDIUM_BEGIN) {  // the boundary's own ops (up to the matching END) are not world primitives: the medium evaluates them itself;
+      // their boxes bound the medium (a ray whose stretch inside that box misses [t_min, closest] cannot draw: constant_medium.rs:43-47)
+      if (in_medium >= 0 || op.skip <= pc + 1 || op.skip > ops.size()) return false;
+      FastMedium fm{pc, pushes.empty() ? NONE : pushes.back(), 0u, 0u, 0u, NONE};
+      {  // classify the boundary: PUSH* (PLANAR+ | SPHERE) POP*
+        uint32_t q = pc + 1, end = op.skip - 1, chain_in = fm.chain, depth = 0;
+        auto code_at = [&](uint32_t i) { return ops[i].code & 0xFFu; };
+        while (q < end && (code_at(q) == OP_PUSH_TRANSLATE || code_at(q) == OP_PUSH_TRANSFORM)) chain_in = q++, depth++;
+        const uint32_t first = q;
+        uint32_t shape = 0;
+        if (q < end && code_at(q) == OP_SPHERE) q++, shape = 2;
+        else {
+          while (q < end && code_at(q) == OP_PLANAR && d.planars[ops[q].a].kind != RL_PLANAR_PLANE &&
+                 !(d.planars[ops[q].a].kind == RL_PLANAR_TRIANGLE && d.planars[ops[q].a].has_normals))
+            q++;
+          if (q > first) shape = 1;
+        }
+        const uint32_t count = q - first;
+        uint32_t pops = 0;
+        while (q < end && (code_at(q) == OP_POP_TRANSLATE || code_at(q) == OP_POP_TRANSFORM)) q++, pops++;
+        if (shape && q == end && pops == depth) fm.shape = shape, fm.first = first, fm.count = count, fm.chain_in = chain_in;
+      }
+      out.media.push_back(fm);
+      in_medium = (int)out.media.size() - 1, medium_end = op.skip - 1;
+      continue;
+    }
+    if (in_medium >= 0 && pc == medium_end) {  // the OP_MEDIUM_END
+      in_medium = -1, cur_seg++;
       continue;
     }
     if (kind == OP_PUSH_TRANSLATE || kind == OP_PUSH_TRANSFORM) pushes.push_back(pc);
@@ -382,12 +408,18 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     else if (kind == OP_BOX_PLANAR) ok = add_planar(op.a, pc) && (op.b == NONE || add_planar(op.b, pc));
     if (!ok) return false;
   }
-  const size_t n = items.size();
-  if (n >= 0x3FFFFFF0u || out.media.size() >= 0x10000u) return false;
+  if (in_medium >= 0) return false;
+  // world items first (program order), the media's boundary parts behind them
+  std::stable_partition(items.begin(), items.end(), [](const GItem &g) { return g.medium < 0; });
+  const size_t n_all = items.size();
+  size_t n = 0;
+  while (n < n_all && items[n].medium < 0) n++;
+  if (n_all >= 0x3FFFFFF0u || out.media.size() >= 0x10000u) return false;
   const size_t n_seg = out.media.size() + 1;
-  if (n == 0) {
+  if (n_all == 0) {
     out.ok = true, out.root = NONE, out.r_safe = 1e30f;
     out.seg_roots.assign(n_seg, NONE);
+    out.stage_roots.assign(2 * n_seg - 1, NONE);
     return true;
   }
   for (const GItem &g : items)
@@ -397,7 +429,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   // normal-check bounds hold for ray origins within r_safe of the centre
   double c[3] = {0, 0, 0};
   for (const GItem &g : items)
-    for (int ax = 0; ax < 3; ax++) c[ax] += 0.5 * (g.box.lo[ax] + g.box.hi[ax]) / (double)n;
+    for (int ax = 0; ax < 3; ax++) c[ax] += 0.5 * (g.box.lo[ax] + g.box.hi[ax]) / (double)n_all;
   const double u = 1.1102230246251565e-16;
   auto far_of = [&](const GItem &g) {  // farthest point of the item's world box from the centre
     double s = 0.0;
@@ -430,9 +462,9 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     if (admissible(r_safe + step)) r_safe += step;
   r_safe = std::fmin(r_safe, 1e18);
   // ---- padded binary32 boxes
-  std::vector<Box> pb(n);
+  std::vector<Box> pb(n_all);
   double cabs = std::fmax(std::fabs(c[0]), std::fmax(std::fabs(c[1]), std::fabs(c[2])));
-  for (size_t i = 0; i < n; i++) {
+  for (size_t i = 0; i < n_all; i++) {
     const GItem &g = items[i];
     double extra = 0.0;
     if (g.it.kind == 0) {  // object-space guard pad, mapped to world space by the forward norm bound (<= 1e5 * sqrt(3) per level, folded into ninv's reciprocal is not available: use the world box growth factor)
@@ -626,6 +658,22 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
       if (broots[sg] != NONE && !(broots[sg] & FASTG_LEAF)) out.seg_roots[sg] = fold(broots[sg]);
   }
   out.qroot = out.seg_roots[0];
+  // ---- stages of a ray's walk: segment 0's tree, medium 0, segment 1's tree, ...; a medium is a one-child node whose box is the union of
+  // its boundary parts' padded boxes (a boundary without bounded parts can never be hit: no stage)
+  out.stage_roots.assign(2 * n_seg - 1, NONE);
+  for (size_t sg = 0; sg < n_seg; sg++) out.stage_roots[2 * sg] = out.seg_roots[sg];
+  for (size_t k = 0; k + 1 < n_seg; k++) {
+    Box mb = EMPTY;
+    bool any = false;
+    for (size_t i = n; i < n_all; i++)
+      if (items[i].medium == (int)k) mb.grow(pb[i]), any = true;
+    if (!any) continue;
+    FastNodeQ q{};
+    for (int ax = 0; ax < 3; ax++) q.lo[ax][0] = round_down(mb.lo[ax]), q.hi[ax][0] = round_up(mb.hi[ax]);
+    q.child[0] = FASTG_LEAF | FASTG_MEDIUM | (uint32_t)k, q.child[1] = q.child[2] = q.child[3] = NONE;
+    out.stage_roots[2 * k + 1] = (uint32_t)out.qnodes.size();
+    out.qnodes.push_back(q);
+  }
   // ---- eight-wide form with quantised boxes (FastNodeO): fold until eight children are held (largest box first), then put every child's
   // box on the node's 8-bit grid, rounded OUTWARDS — checked below in exact arithmetic (every term is a dyadic rational that binary64 holds)
   out.onodes.clear();

@@ -177,6 +177,12 @@ static const uint32_t FASTG_MEDIUM = 0x40000000u;  // entry / `best`: a medium (
 struct FastMedium {
   uint32_t pc;     // its OP_MEDIUM_BEGIN
   uint32_t chain;  // pc of the innermost PUSH op around it (NONE: world space)
+  // the boundary's shape, where it is simple enough for both boundary hits of constant_medium.rs:28-40 to come out of ONE evaluation:
+  // 1 = PUSH* PLANAR+ POP* (quads / triangles without vertex normals, e.g. a rotated and translated box of six quads),
+  // 2 = PUSH* SPHERE POP*, 0 = anything else (the reference's fold over the boundary's ops, twice)
+  uint32_t shape;
+  uint32_t first, count;  // shape 1, 2: pc of the first primitive op, number of primitive ops
+  uint32_t chain_in;      // shape 1, 2: pc of the innermost PUSH op around the primitives (NONE: world space)
 };
 struct FastGeneral {
   std::vector<FastNodeG> nodes;
@@ -190,6 +196,7 @@ struct FastGeneral {
   uint32_t qroot = NONE;     // ... in the four-wide form (= seg_roots[0])
   std::vector<uint32_t> seg_roots;  // four-wide root entry of every segment (one segment, no media: {qroot})
   std::vector<FastMedium> media;    // seg_roots.size() == media.size() + 1
+  std::vector<uint32_t> stage_roots;  // what a ray walks, in order: seg_roots[0], medium 0's box node, seg_roots[1], ... (2 * media.size() + 1 entries)
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
   float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)
   float radius = 0, pad_k = 0;  // ... box growth for those rays = pad_k * (distance to centre + radius)^2 (world units)

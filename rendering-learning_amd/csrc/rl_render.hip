@@ -486,7 +486,7 @@ static rl_scene *upload_rtiow(const std::shared_ptr<const HostRtiow> &H, int ctx
       (!H->lops.empty() && ((rc = upload(H->lops, &s->d_lops)) || (rc = upload(H->sphere_flat, &s->d_sphere_flat)))) ||
       (!H->cops.empty() && ((rc = upload(H->cops, &s->d_cops)) || (rc = upload(H->movbits, &s->d_movbits)))) ||
       (H->fast_root != FAST_NONE && ((rc = upload(H->fast_nodes, &s->d_fast_nodes)) || (rc = upload(H->fast_leaf_boxes, &s->d_fast_leaf_boxes)))) ||
-      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.onodes, &s->d_fg_onodes)) || (rc = upload(H->fg.seg_roots, &s->d_fg_seg_roots)) ||
+      (H->fg.ok && ((rc = upload(H->fg.qnodes, &s->d_fg_nodes)) || (rc = upload(H->fg.onodes, &s->d_fg_onodes)) || (rc = upload(H->fg.stage_roots, &s->d_fg_seg_roots)) ||
                     (rc = upload(H->fg.media, &s->d_fg_media)) || (rc = upload(H->fg.items, &s->d_fg_items)) || (rc = upload(H->fg.item_spheres, &s->d_fg_spheres)) || (rc = upload(H->fg.item_material, &s->d_fg_material))))) {
     destroy_one(s);
     return nullptr;
@@ -754,7 +754,7 @@ static int fill_rtiow_params(const rl_scene *scene, const rl_rtiow_camera *cam, 
 #ifdef RL_EXPERIMENTAL
   P.fg_onodes = scene->d_fg_onodes, P.fg_oroot = H.fg.oroot;
 #endif
-  P.fg_seg_roots = scene->d_fg_seg_roots, P.fg_media = scene->d_fg_media, P.fg_n_seg = (uint32_t)H.fg.seg_roots.size();
+  P.fg_seg_roots = scene->d_fg_seg_roots, P.fg_media = scene->d_fg_media, P.fg_n_seg = (uint32_t)H.fg.stage_roots.size();
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;
@@ -1325,6 +1325,10 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
       if (f.has_box && !inside(f.box, ulo, uhi)) out16[7]++;  // a node's box (held by its parent) contains its children's boxes
     }
     for (uint32_t c : seen) out16[5] += c > 1u ? 1u : 0u, out16[6] += c == 0u ? 1u : 0u;
+    // media: [14] = how many, [15] = one byte per medium (the first eight): FastMedium::shape, + 0x10 when the medium has a box node
+    out16[14] = fg.media.size();
+    for (size_t k = 0; k < fg.media.size() && k < 8; k++)
+      out16[15] |= (unsigned long long)(fg.media[k].shape | (fg.stage_roots[2 * k + 1] != NONE ? 0x10u : 0u)) << (8 * k);
   }
   if (H->fast_root != FAST_NONE) {
     const std::vector<FastNode> &nodes = H->fast_nodes;

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
   double time = 0.0, closest = INF;
   uint32_t pc = 0, best = NONE, depth = 0, sp = 0, steps = 0;
   const uint32_t step_budget = P.tune[3];
-  uint32_t seg = 0, pos0 = 0, ray_flags = 0;  // MEDIA: segment being walked, ChaCha word position at the start of the ray, panic sites of its boundary walks
+  uint32_t seg = 0, pos0 = 0, ray_flags = 0;  // MEDIA: stage being walked, ChaCha word position at the start of the ray, panic sites of its boundary walks
   bool amb = false;
   // rays that start farther than r_safe from the scene's centre (e.g. inside a huge ground sphere): the boxes' padding was sized for
   // origins inside r_safe, so such a ray widens every box interval by `grow` and does NOT prune by the closest hit — every sphere its
@@ -217,11 +217,9 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
 
   auto go = [&](uint32_t e) {  // continue with entry e: an inner node (TRAV), an item (LEAF), or nothing left (SHADE)
     if (++steps > step_budget) amb = true, e = NONE;
-    if (MEDIA && e == NONE && !amb && seg + 1u < P.fg_n_seg) {  // this segment is done: the medium behind it (LEAF evaluates it), then the next one
-      pc = FASTG_LEAF | FASTG_MEDIUM | seg;
-      state = ST_LEAF;
-      return;
-    }
+    // MEDIA: this stage is done: the next one (a segment's tree, or a medium behind its box node: P.fg_seg_roots holds FastGeneral::stage_roots)
+    if (MEDIA && !amb)
+      while (e == NONE && seg + 1u < P.fg_n_seg) e = P.fg_seg_roots[++seg];
     if (e == NONE) {
 #ifdef RL_FASTG_VERIFY
       if (false) {
@@ -396,7 +394,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
             const uint4 ch = *(const uint4 *)(nd + 6);
             float k0, k1, k2, k3;
             const bool h0 = !missed(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, k0);  // slot 0 and 1 are never empty
-            const bool h1 = !missed(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, k1);
+            const bool h1 = !missed(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, k1) && (!MEDIA || ch.y != NONE);  // (a medium's box node has one child)
             const bool h2 = !missed(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, k2) && ch.z != NONE;
             const bool h3 = !missed(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, k3) && ch.w != NONE;
             const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
@@ -431,20 +429,87 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
           const FastMedium fm = P.fg_media[k];
           const DevOp &mop = ops[fm.pc];
           const rl_medium &m = P.media[mop.a];
-          D3 o, d;
-          replay_chain(P, ops, fm.chain, wo, wd, o, d);
+          D3 om, dm, o, d;  // the ray in the medium's own scope (its length enters the free path), and in the scope of the boundary's parts
+          replay_chain(P, ops, fm.chain, wo, wd, om, dm);
+          o = om, d = dm;
           Rec r1, r2;
           r1.t = INF, r1.any = false, r1.pc = 0, r2.t = INF, r2.any = false, r2.pc = 0;
           GenCounters gc{0, 0, 0, 0, 0};
-          auto nodraw = []() { return 0.0; };
-          general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, o, d, wo, wd, time, -INF, r1, gc, nodraw);  // boundary.hit(r, universe)
-          if (r1.any) general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, o, d, wo, wd, time, r1.t + 1e-4, r2, gc, nodraw);
+          bool folded = false;  // both boundary hits (constant_medium.rs:28-40) still to be found by the reference's fold over the boundary's ops
+          if (fm.shape == 1u) {
+            // PUSH* PLANAR+ POP*: a planar's t and its inside test do not depend on the interval, so ONE evaluation of every part gives
+            // both hits: boundary.hit(r, universe).t = the smallest valid t, boundary.hit(r, [t1 + 1e-4, inf)).t = the smallest valid t
+            // >= t1 + 1e-4 (the fold's `t <= closest` replaces on ties, which changes the part, not t; the POPs touch p and the normal
+            // only, and their panic site needs |M^-T n|^2 <= 1e-16, which the builder's norm bound 1e5 on every transform excludes).
+            // The three smallest t are kept; a fourth hit with all three within 1e-4 of each other goes the general way.
+            if (fm.chain_in != fm.chain) replay_chain(P, ops, fm.chain_in, wo, wd, o, d);
+            double ta = INF, tb = INF, tc = INF;
+            uint32_t cnt = 0;
+#pragma unroll 1
+            for (uint32_t i = 0; i < fm.count; i++) {
+              const DevPlanar &pl = P.planars[ops[fm.first + i].a];
+              const D3 normal = ld3(pl.normal);
+              const double denom = dot(normal, d);
+              if (fabs(denom) < 1e-8) continue;
+              const double t = (pl.d - dot(normal, o)) / denom;
+              if (!(-INF <= t && t <= INF)) continue;
+              const D3 hp = (o + d * t) - ld3(pl.q);
+              const D3 w = ld3(pl.w);
+              const double alpha = dot(w, cross(hp, ld3(pl.v))), beta = dot(w, cross(ld3(pl.u), hp));
+              const bool in = pl.kind == RL_PLANAR_QUAD ? (0.0 <= alpha && alpha <= 1.0 && 0.0 <= beta && beta <= 1.0) : (0.0 <= alpha && 0.0 <= beta && alpha + beta <= 1.0);
+              if (!in) continue;
+              cnt++;
+              if (t < ta) tc = tb, tb = ta, ta = t;
+              else if (t < tb) tc = tb, tb = t;
+              else if (t < tc) tc = t;
+            }
+            const double thr = ta + 1e-4;
+            folded = true;
+            if (cnt >= 1u) r1.any = true, r1.t = ta;
+            if (cnt >= 2u && thr <= tb) r2.any = true, r2.t = tb;
+            else if (cnt >= 3u && thr <= tc) r2.any = true, r2.t = tc;
+            else if (cnt > 3u) folded = false, r1.any = false, r1.t = INF;
+          } else if (fm.shape == 2u) {
+            // PUSH* SPHERE POP*: both roots out of one discriminant (sphere.rs:32-75 twice, with its normal check at either hit)
+            if (fm.chain_in != fm.chain) replay_chain(P, ops, fm.chain_in, wo, wd, o, d);
+            const uint32_t payload = ops[fm.first].a;
+            const DevSphere &s = P.spheres[payload & SPH_INDEX];
+            const D3 c0 = ld3(s.c0);
+            const D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+            const D3 oc = o - center;
+            const double a = len2(d), half_b = dot(oc, d), c = len2(oc) - s.r2;
+            const double disc = half_b * half_b - a * c;
+            folded = true;
+            if (!(disc < 0.0)) {
+              const double sq = sqrt(disc);
+              const double r_l = (-half_b - sq) / a, r_u = (-half_b + sq) / a;
+              auto unit_flag = [&](double t) {
+                const D3 outward = ((o + d * t) - center) * s.inv_r;
+                const double l2 = len2(outward);
+                return !(l2 == 1.0 || fabs(l2 - 1.0) <= 1e-5);
+              };
+              if (-INF <= r_l && r_l <= INF) r1.any = true, r1.t = r_l;
+              else if (-INF <= r_u && r_u <= INF) r1.any = true, r1.t = r_u;
+              if (r1.any) {
+                gc.flagged += unit_flag(r1.t) ? 1u : 0u;
+                const double thr = r1.t + 1e-4;
+                if (thr <= r_l && r_l <= INF) r2.any = true, r2.t = r_l;
+                else if (thr <= r_u && r_u <= INF) r2.any = true, r2.t = r_u;
+                if (r2.any) gc.flagged += unit_flag(r2.t) ? 1u : 0u;
+              }
+            }
+          }
+          if (!folded) {
+            auto nodraw = []() { return 0.0; };
+            general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, om, dm, wo, wd, time, -INF, r1, gc, nodraw);  // boundary.hit(r, universe)
+            if (r1.any) general_trace<false, false>(P, ops, fm.pc + 1u, mop.skip - 1u, om, dm, wo, wd, time, r1.t + 1e-4, r2, gc, nodraw);
+          }
           ray_flags += (uint32_t)gc.flagged;
           if (r1.any && r2.any) {
             double t1 = fmax(r1.t, 1e-10), t2 = fmin(r2.t, closest);
             if (!(t1 >= t2)) {
               t1 = fmax(t1, 0.0);
-              const double ray_length = sqrt(len2(d));
+              const double ray_length = sqrt(len2(dm));
               const double distance_inside_boundary = (t2 - t1) * ray_length;
               const double hit_distance = m.neg_inv_density * log(rng.gen_f64());  // the draw, where the reference's fold makes it
               if (!(hit_distance > distance_inside_boundary)) {
@@ -455,8 +520,7 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
               }
             }
           }
-          seg++;
-          go(P.fg_seg_roots[seg]);
+          go(pop());  // (nothing is pending behind a medium's node: the next stage)
         } else {
         const uint32_t item = pc & ~FASTG_LEAF;
         const FastItem it = items[item];

@@ -159,3 +159,57 @@ def test_gpu_wave_scheduled_medium_scope_equals_nested_loop_kernel(rl, oracle, s
         cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
         assert cs["rays"] == stats[0]["rays"] and cs["rng_words"] == stats[0]["rng_words"]
         assert np.abs(frames[0] - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
+
+
+def _boundary_shapes_scene(b):
+    """Media behind every kind of boundary the fast traversal tells apart (rl_program.h FastMedium::shape): a sphere, a moving sphere under a
+    Translate, a rotated box of six quads, a tetrahedron of triangles, THREE coincident boxes in one list (six hits per line, the three
+    nearest equal: the one-pass evaluation must hand over to the reference's fold), a Bvh of spheres (general shape), and a medium whose
+    boundary is an open surface (one quad: never two hits, never a draw)."""
+    white = b.lambertian(b.solid((0.73, 0.73, 0.73)))
+    fog = lambda c: b.isotropic(b.solid(c))
+    flat = b.flat()
+
+    def box(lo, hi, m):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        dx, dy, dz = (x1 - x0, 0, 0), (0, y1 - y0, 0), (0, 0, z1 - z0)
+        return [b.quad((x0, y0, z1), dx, dy, m), b.quad((x1, y0, z1), (0, 0, -(z1 - z0)), dy, m), b.quad((x1, y0, z0), (-(x1 - x0), 0, 0), dy, m),
+                b.quad((x0, y0, z0), dz, dy, m), b.quad((x0, y1, z1), dx, (0, 0, -(z1 - z0)), m), b.quad((x0, y0, z0), dx, dz, m)]
+    floor = b.quad((-20, -1, -20), (40, 0, 0), (0, 0, 40), white)
+    lamp = b.quad((-3, 8, -3), (6, 0, 0), (0, 0, 6), b.diffuse_light(b.solid((6, 6, 6))))
+    m_sphere = b.constant_medium(b.sphere((-6, 0.5, 0), 1.5, flat), 0.5, fog((0.9, 0.2, 0.2)))
+    m_moving = b.constant_medium(b.translate(b.sphere((0, 0, 0), 1.2, flat, center2=(0.4, 0.3, 0)), (-2.5, 0.5, 1.0)), 0.7, fog((0.2, 0.9, 0.2)))
+    m_box = b.constant_medium(b.translate(b.rotate_y(b.list(box((0, 0, 0), (2, 2.5, 2), flat)), 25.0), (0.5, -1, -1)), 0.6, fog((0.2, 0.2, 0.9)))
+    tet = [(4, -1, -1), (6, -1, -1), (5, -1, 1), (5, 1.5, 0)]
+    tri = lambda i, j, k: b.triangle(tet[i], tuple(np.subtract(tet[j], tet[i])), tuple(np.subtract(tet[k], tet[i])), flat)
+    m_tet = b.constant_medium(b.list([tri(0, 1, 2), tri(0, 1, 3), tri(1, 2, 3), tri(2, 0, 3)]), 0.9, fog((0.9, 0.9, 0.2)))
+    m_triple = b.constant_medium(b.list(box((7, -1, -1), (9, 1, 1), flat) * 3), 0.8, fog((0.2, 0.9, 0.9)))
+    m_general = b.constant_medium(b.bvh([b.sphere((-4, 3.5, -2), 1.0, flat), b.sphere((-3, 3.5, -2), 1.0, flat), b.sphere((-2, 3.5, -2), 1.0, flat)]), 0.8,
+                                  fog((0.9, 0.2, 0.9)))
+    m_open = b.constant_medium(b.quad((2, 2, -2), (2, 0, 0), (0, 2, 0), flat), 5.0, fog((1, 1, 1)))
+    ball = b.sphere((2.5, 3.5, 1.0), 0.8, b.dielectric(1.5))
+    return b.list([floor, m_sphere, lamp, m_moving, b.bvh([m_box, ball, m_tet]), m_triple, m_general, m_open])
+
+
+@pytest.mark.gpu
+def test_gpu_fast_traversal_with_every_boundary_shape_equals_counting_kernel_and_oracle(rl, oracle):
+    import torch
+    world = rl.World.build(_boundary_shapes_scene)
+    p = rl.CameraParams(aspect_ratio=1.6, image_width=96, samples_per_pixel=20, max_depth=12, vfov=45.0, lookfrom=(1, 4, 16), lookat=(1, 1, 0),
+                        background=(0.3, 0.4, 0.6), seed=17)
+    cam = rl.Camera(p)
+    out16 = (rl.api.C.c_uint64 * 16)()
+    rl.api.render_lib().rl_debug_host_structures.argtypes = [rl.api.C.c_void_p, rl.api.C.c_void_p]
+    assert rl.api.render_lib().rl_debug_host_structures(world.desc, out16) == 0 and (out16[0] & 2)  # the general fast structure exists
+    gs, cs = {}, {}
+    counting = cam.render(world, stats=gs).data
+    buf = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+    cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    st = rl.api.render_status(world)
+    fast = buf.cpu().numpy()
+    assert np.array_equal(fast.view(np.uint64), counting.view(np.uint64)), int((fast != counting).any(axis=2).sum())
+    assert st["rays"] == gs["rays"] and st["flagged"] == gs["flagged"]
+    cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+    for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
+        assert gs[k] == cs[k], (k, gs[k], cs[k])
+    assert np.abs(counting - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())

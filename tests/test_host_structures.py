@@ -16,7 +16,7 @@ def _check(rl, world):
     rc = L.rl_debug_host_structures(world.desc, out)
     assert rc == 0, L.rl_last_error().decode()
     keys = ("flags", "items", "binary_nodes", "quad_nodes", "leaves", "dups", "missing", "box_violations", "quad_depth",
-            "s_inner", "s_leaves", "s_bad_reach", "s_box_violations", "s_depth")
+            "s_inner", "s_leaves", "s_bad_reach", "s_box_violations", "s_depth", "media", "media_shapes")
     return dict(zip(keys, list(out)))
 
 
@@ -75,6 +75,13 @@ def test_scenes_that_must_stay_on_the_reference_order_kernels(rl):
     # whose own boundary quads are not world primitives — and every segment's tree is checked like the single one of a scene without media
     smoke = _check(rl, rl.World.example_scene("cornell_smoke"))
     assert smoke["flags"] == 2 and smoke["items"] == 6 and smoke["leaves"] == 6 and smoke["dups"] == 0 and smoke["missing"] == 0 and smoke["box_violations"] == 0
+    # ... both media sit behind a box node, and their boundaries (Translate(RotateY([Quad; 6]))) are recognised as planar lists (shape 1)
+    assert smoke["media"] == 2 and smoke["media_shapes"] == 0x1111
+    final = _check(rl, rl.World.example_scene("final_scene", rgb8=_tex()))  # two sphere boundaries (shape 2)
+    assert final["flags"] == 2 and final["media"] == 2 and final["media_shapes"] == 0x1212 and final["box_violations"] == 0
+    import test_constant_medium as tcm  # sphere, moving sphere under a Translate, rotated box, tetrahedron, 18 quads, a Bvh of spheres (general), one quad
+    shapes = _check(rl, rl.World.build(tcm._boundary_shapes_scene))
+    assert shapes["flags"] == 2 and shapes["media"] == 7 and shapes["media_shapes"] == 0x11101111111212
     assert _check(rl, rl.World.example_scene("checkered_spheres"))["flags"] == 1
 
     def vanishing(b):  # a smooth triangle whose interpolated normal passes through zero
