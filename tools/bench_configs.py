@@ -95,8 +95,12 @@ if "examples" in which:  # not BASELINE configs: the reference's other example s
     tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
     for name, kw in (("checkered_spheres", {}), ("quads", {}), ("flat_world", {}), ("cornell_box", {}), ("cornell_smoke", {}),
                      ("teapot", dict(obj_text=open(os.path.join(G, "teapot-low.obj"), "rb").read())), ("final_scene", dict(rgb8=tex))):
+        if os.environ.get("EX_ONLY") and name not in os.environ["EX_ONLY"].split(","):
+            continue
         w = rl.World.example_scene(name, **kw)
         p = w.params
+        if os.environ.get("EX_WIDTH"):  # the same scene at another frame size (how much of a figure is the small frame's latency)
+            p.image_width = int(os.environ["EX_WIDTH"])
         rtiow("examples/%s.rs %dx%d" % (name, p.image_width, int(p.image_width / p.aspect_ratio)), w, p, 50)
 if "cfg4" in which or "cfg5" in which:
     tex = np.asarray(Image.open(os.path.join(G, "spot_texture.png")).convert("RGB"))
