@@ -233,6 +233,7 @@ void to_world(const rl_rtiow_scene_desc &d, const std::vector<DevOp> &ops, const
 struct GItem {
   uint32_t seg = 0;  // segment of the program the occurrence belongs to (FastGeneral::seg_roots)
   int medium = -1;   // >= 0: not a world item but part of that medium's boundary (only its padded box is used: FastGeneral::stage_roots)
+  bool plane = false;  // an unbounded Plane: no box, in no tree — a stage of its own that every ray visits (FastGeneral::stage_roots)
   FastItem it;
   Box box;       // world-space bounds (unpadded)
   double r = 0;  // spheres: radius; else 0
@@ -341,10 +342,17 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   };
   auto add_planar = [&](uint32_t idx, uint32_t pc) -> bool {
     const rl_planar &pl = d.planars[idx];
-    if (pl.kind != RL_PLANAR_QUAD && pl.kind != RL_PLANAR_TRIANGLE) return false;  // an unbounded Plane has no box
+    if (pl.kind != RL_PLANAR_QUAD && pl.kind != RL_PLANAR_TRIANGLE && pl.kind != RL_PLANAR_PLANE) return false;
     GItem g;
     g.it.kind = 1, g.it.payload = idx, g.it.op_pc = pc, g.seg = cur_seg, g.medium = in_medium;
     chain_of(g);
+    if (pl.kind == RL_PLANAR_PLANE) {  // plane.rs:51-100 without the quad's interior test: unbounded, so no box and no place in a tree
+      for (int ax = 0; ax < 3; ax++)
+        if (!(std::isfinite(pl.q[ax]) && std::isfinite(pl.u[ax]) && std::isfinite(pl.v[ax]))) return false;
+      g.plane = true, g.box = EMPTY;
+      items.push_back(g);
+      return true;
+    }
     double pts[4][3];
     for (int ax = 0; ax < 3; ax++) {
       pts[0][ax] = pl.q[ax], pts[1][ax] = pl.q[ax] + pl.u[ax], pts[2][ax] = pl.q[ax] + pl.v[ax], pts[3][ax] = pl.q[ax] + pl.u[ax] + pl.v[ax];
@@ -410,7 +418,12 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   }
   if (in_medium >= 0) return false;
   // world items first (program order), the media's boundary parts behind them
-  std::stable_partition(items.begin(), items.end(), [](const GItem &g) { return g.medium < 0; });
+  std::stable_sort(items.begin(), items.end(), [](const GItem &a, const GItem &b) {  // (within a segment: its planes first, then the boxed items in program order)
+    if ((a.medium >= 0) != (b.medium >= 0)) return a.medium < 0;
+    if (a.medium >= 0) return false;
+    if (a.seg != b.seg) return a.seg < b.seg;
+    return a.plane && !b.plane;
+  });
   const size_t n_all = items.size();
   size_t n = 0;
   while (n < n_all && items[n].medium < 0) n++;
@@ -419,17 +432,23 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   if (n_all == 0) {
     out.ok = true, out.root = NONE, out.r_safe = 1e30f;
     out.seg_roots.assign(n_seg, NONE);
-    out.stage_roots.assign(2 * n_seg - 1, NONE);
+    out.stage_roots.assign(1, NONE);
+    out.media_stage.assign(n_seg - 1, NONE);
     return true;
   }
-  for (const GItem &g : items)
+  size_t n_boxed = 0;
+  for (const GItem &g : items) {
+    if (g.plane) continue;
+    n_boxed++;
     for (int ax = 0; ax < 3; ax++)
       if (!(std::fabs(g.box.lo[ax]) <= 1e30 && std::fabs(g.box.hi[ax]) <= 1e30)) return false;
+  }
   // ---- frame: centre = mean of the item centres; r_safe = (nearly) the largest radius for which every sphere's padding and
   // normal-check bounds hold for ray origins within r_safe of the centre
   double c[3] = {0, 0, 0};
   for (const GItem &g : items)
-    for (int ax = 0; ax < 3; ax++) c[ax] += 0.5 * (g.box.lo[ax] + g.box.hi[ax]) / (double)n_all;
+    for (int ax = 0; ax < 3; ax++)
+      if (!g.plane) c[ax] += 0.5 * (g.box.lo[ax] + g.box.hi[ax]) / (double)n_boxed;
   const double u = 1.1102230246251565e-16;
   auto far_of = [&](const GItem &g) {  // farthest point of the item's world box from the centre
     double s = 0.0;
@@ -466,6 +485,8 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   double cabs = std::fmax(std::fabs(c[0]), std::fmax(std::fabs(c[1]), std::fabs(c[2])));
   for (size_t i = 0; i < n_all; i++) {
     const GItem &g = items[i];
+    pb[i] = EMPTY;
+    if (g.plane) continue;
     double extra = 0.0;
     if (g.it.kind == 0) {  // object-space guard pad, mapped to world space by the forward norm bound (<= 1e5 * sqrt(3) per level, folded into ninv's reciprocal is not available: use the world box growth factor)
       double L, M;
@@ -587,10 +608,12 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     for (size_t sg = 0; sg < n_seg; sg++) {
       size_t hi = lo;
       while (hi < n && items[hi].seg == sg) hi++;
-      if (hi - lo == 1) broots[sg] = FASTG_LEAF | (uint32_t)lo;  // a single occurrence: rays start in LEAF, no node at all
-      else if (hi > lo) {
+      size_t mid = lo;  // the segment's planes come first: stages of their own, not in the tree
+      while (mid < hi && items[mid].plane) mid++;
+      if (hi - mid == 1) broots[sg] = FASTG_LEAF | (uint32_t)mid;  // a single occurrence: rays start in LEAF, no node at all
+      else if (hi > mid) {
         Box all;
-        broots[sg] = build(lo, hi, FASTG_MAX_DEPTH, all);
+        broots[sg] = build(mid, hi, FASTG_MAX_DEPTH, all);
       }
       lo = hi;
     }
@@ -602,6 +625,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   {
     double rmin = INFINITY, radius = 0.0;
     for (const GItem &g : items) {
+      if (g.plane) continue;
       radius = std::fmax(radius, far_of(g));
       if (g.it.kind == 0) rmin = std::fmin(rmin, g.r / g.ninv);  // object-space pad seen from world space: conservative through the chain norms
     }
@@ -660,19 +684,37 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   out.qroot = out.seg_roots[0];
   // ---- stages of a ray's walk: segment 0's tree, medium 0, segment 1's tree, ...; a medium is a one-child node whose box is the union of
   // its boundary parts' padded boxes (a boundary without bounded parts can never be hit: no stage)
-  out.stage_roots.assign(2 * n_seg - 1, NONE);
-  for (size_t sg = 0; sg < n_seg; sg++) out.stage_roots[2 * sg] = out.seg_roots[sg];
-  for (size_t k = 0; k + 1 < n_seg; k++) {
-    Box mb = EMPTY;
-    bool any = false;
-    for (size_t i = n; i < n_all; i++)
-      if (items[i].medium == (int)k) mb.grow(pb[i]), any = true;
-    if (!any) continue;
-    FastNodeQ q{};
-    for (int ax = 0; ax < 3; ax++) q.lo[ax][0] = round_down(mb.lo[ax]), q.hi[ax][0] = round_up(mb.hi[ax]);
-    q.child[0] = FASTG_LEAF | FASTG_MEDIUM | (uint32_t)k, q.child[1] = q.child[2] = q.child[3] = NONE;
-    out.stage_roots[2 * k + 1] = (uint32_t)out.qnodes.size();
-    out.qnodes.push_back(q);
+  out.stage_roots.clear();
+  out.media_stage.assign(n_seg - 1, NONE);
+  {
+    size_t it = 0;
+    for (size_t sg = 0; sg < n_seg; sg++) {
+      for (; it < n && items[it].seg == sg; it++)
+        if (items[it].plane) out.stage_roots.push_back(FASTG_LEAF | (uint32_t)it);  // every ray visits an unbounded Plane
+      if (out.seg_roots[sg] != NONE) out.stage_roots.push_back(out.seg_roots[sg]);
+      if (sg + 1 == n_seg) break;
+      const size_t k = sg;
+      Box mb = EMPTY;
+      bool any = false, unbounded = false;
+      for (size_t i = n; i < n_all; i++)
+        if (items[i].medium == (int)k) {
+          any = true;
+          if (items[i].plane) unbounded = true;
+          else mb.grow(pb[i]);
+        }
+      if (!any) continue;  // a boundary without parts can never be hit
+      out.media_stage[k] = (uint32_t)out.stage_roots.size();
+      if (unbounded) {  // a Plane in the boundary: no box, every ray evaluates the medium
+        out.stage_roots.push_back(FASTG_LEAF | FASTG_MEDIUM | (uint32_t)k);
+        continue;
+      }
+      FastNodeQ q{};
+      for (int ax = 0; ax < 3; ax++) q.lo[ax][0] = round_down(mb.lo[ax]), q.hi[ax][0] = round_up(mb.hi[ax]);
+      q.child[0] = FASTG_LEAF | FASTG_MEDIUM | (uint32_t)k, q.child[1] = q.child[2] = q.child[3] = NONE;
+      out.stage_roots.push_back((uint32_t)out.qnodes.size());
+      out.qnodes.push_back(q);
+    }
+    if (out.stage_roots.empty()) out.stage_roots.push_back(NONE);
   }
   // ---- eight-wide form with quantised boxes (FastNodeO): fold until eight children are held (largest box first), then put every child's
   // box on the node's 8-bit grid, rounded OUTWARDS — checked below in exact arithmetic (every term is a dyadic rational that binary64 holds)

@@ -196,7 +196,10 @@ struct FastGeneral {
   uint32_t qroot = NONE;     // ... in the four-wide form (= seg_roots[0])
   std::vector<uint32_t> seg_roots;  // four-wide root entry of every segment (one segment, no media: {qroot})
   std::vector<FastMedium> media;    // seg_roots.size() == media.size() + 1
-  std::vector<uint32_t> stage_roots;  // what a ray walks, in order: seg_roots[0], medium 0's box node, seg_roots[1], ... (2 * media.size() + 1 entries)
+  // what a ray walks, in order: per segment its unbounded Planes (leaf entries: every ray tests them) and its tree, then the medium behind
+  // it (a one-child box node, or the medium's leaf entry itself when its boundary holds a Plane); empty stages are left out
+  std::vector<uint32_t> stage_roots;
+  std::vector<uint32_t> media_stage;  // index of medium k's stage in stage_roots (NONE: the boundary has no parts)
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
   float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)
   float radius = 0, pad_k = 0;  // ... box growth for those rays = pad_k * (distance to centre + radius)^2 (world units)

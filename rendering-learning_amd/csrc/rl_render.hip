@@ -970,7 +970,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
       if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      if (rt.has_media) {  // segments + media (the boundary walks and the Isotropic phase function need the 256-register budget)
+      if (H.fg.stage_roots.size() > 1) {  // several stages (media, unbounded Planes): the boundary walks and the Isotropic phase function need the 256-register budget
         constexpr int NT = 512, SD = 40;
         size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
         rc = trans ? launch_ptr(rtiow_fast_general_kernel<NT, SD, true, false, true>, NT, rb) : launch_ptr(rtiow_fast_general_kernel<NT, SD, false, false, true>, NT, rb);
@@ -1271,7 +1271,7 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
       unsigned depth;
     };
     std::vector<Frame> st;
-    for (uint32_t sr : fg.seg_roots)
+    for (uint32_t sr : fg.stage_roots)  // every stage: plane leaves, segment trees, media (their entries carry FASTG_MEDIUM and are no items)
       if (sr != NONE) st.push_back(Frame{sr, {0, 0, 0, 0, 0, 0}, false, 1u});
     auto inside = [](const float *outer, const double *lo, const double *hi) {
       for (int ax = 0; ax < 3; ax++)
@@ -1282,6 +1282,7 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
       Frame f = st.back();
       st.pop_back();
       out16[8] = std::max<unsigned long long>(out16[8], f.depth);
+      if ((f.e & FASTG_LEAF) && (f.e & FASTG_MEDIUM)) continue;
       if (f.e & FASTG_LEAF) {
         const uint32_t item = f.e & ~FASTG_LEAF;
         out16[4]++;
@@ -1299,6 +1300,9 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
               double c1 = sp.moving ? sp.center1[ax] : sp.center0[ax];
               lo[ax] = std::fmin(sp.center0[ax], c1) - std::fabs(sp.radius), hi[ax] = std::fmax(sp.center0[ax], c1) + std::fabs(sp.radius);
             }
+          } else if (desc->planars[it.payload].kind == RL_PLANAR_PLANE) {
+            out16[7]++;  // an unbounded Plane must not sit below a box
+            continue;
           } else {
             const rl_planar &pl = desc->planars[it.payload];
             for (int ax = 0; ax < 3; ax++) {
@@ -1328,7 +1332,7 @@ int rl_debug_host_structures(const rl_rtiow_scene_desc *desc, unsigned long long
     // media: [14] = how many, [15] = one byte per medium (the first eight): FastMedium::shape, + 0x10 when the medium has a box node
     out16[14] = fg.media.size();
     for (size_t k = 0; k < fg.media.size() && k < 8; k++)
-      out16[15] |= (unsigned long long)(fg.media[k].shape | (fg.stage_roots[2 * k + 1] != NONE ? 0x10u : 0u)) << (8 * k);
+      out16[15] |= (unsigned long long)(fg.media[k].shape | (fg.media_stage[k] != NONE && !(fg.stage_roots[fg.media_stage[k]] & FASTG_LEAF) ? 0x10u : 0u)) << (8 * k);
   }
   if (H->fast_root != FAST_NONE) {
     const std::vector<FastNode> &nodes = H->fast_nodes;

@@ -120,9 +120,11 @@ __device__ __forceinline__ void fastg_planar_hit(const DevPlanar &pl, D3 o, D3 d
   if (pl.kind == RL_PLANAR_QUAD) {
     inside = 0.0 <= alpha && alpha <= 1.0 && 0.0 <= beta && beta <= 1.0;
     edge = fabs(alpha) <= e || fabs(alpha - 1.0) <= e || fabs(beta) <= e || fabs(beta - 1.0) <= e;
-  } else {  // triangle (build_fast_general admits no unbounded Plane)
+  } else if (pl.kind == RL_PLANAR_TRIANGLE) {
     inside = 0.0 <= alpha && 0.0 <= beta && alpha + beta <= 1.0;
     edge = fabs(alpha) <= e || fabs(beta) <= e || fabs(alpha + beta - 1.0) <= e;
+  } else {  // an unbounded Plane (a stage of its own: FastGeneral::stage_roots): plane.rs:51-100 has no interior test, and no box anywhere
+    inside = true, edge = false;
   }
   if (!inside) return;
   if (edge) amb = true;  // an edge-grazing hit may or may not pass the reference's own leaf box (the exact bound of the vertices)

@@ -213,3 +213,47 @@ def test_gpu_fast_traversal_with_every_boundary_shape_equals_counting_kernel_and
     for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
         assert gs[k] == cs[k], (k, gs[k], cs[k])
     assert np.abs(counting - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
+
+
+def _planes_scene(b):
+    """Unbounded Planes (plane.rs: no interior test, AABB::universe) everywhere the fast traversal has to cope with them: in a list, inside
+    a Bvh (where they drag every enclosing box to the universe), under a Translate / rotation, between two media (so that their segment
+    matters), and as part of a medium's boundary (fog between two planes: no box node, every ray evaluates it)."""
+    grey = b.lambertian(b.checker(0.8, b.solid((0.2, 0.3, 0.1)), b.solid((0.9, 0.9, 0.9))))
+    red = b.lambertian(b.solid((0.8, 0.2, 0.2)))
+    flat = b.flat()
+    ground = b.plane((0, -1, 0), (1, 0, 0), (0, 0, 1), grey)
+    wall = b.translate(b.rotate_y(b.plane((0, 0, -6), (1, 0, 0), (0, 1, 0), red), 20.0), (0.5, 0, 0))
+    mirror = b.plane((-7, 0, 0), (0, 0, 1), (0, 1, 0), b.metal((0.8, 0.8, 0.9), 0.05))
+    lamp = b.quad((-2, 5, -2), (4, 0, 0), (0, 0, 4), b.diffuse_light(b.solid((5, 5, 5))))
+    balls = [b.sphere((x, -0.4, z), 0.6, m) for x, z, m in ((-2, 0, b.dielectric(1.5)), (0, -1, red), (2, 0.5, b.metal((0.7, 0.6, 0.5), 0.0)))]
+    slab = b.constant_medium(b.list([b.plane((0, 0.2, 0), (1, 0, 0), (0, 0, 1), flat), b.plane((0, 0.9, 0), (1, 0, 0), (0, 0, 1), flat)]), 0.15,
+                             b.isotropic(b.solid((0.8, 0.8, 1.0))))
+    puff = b.constant_medium(b.sphere((3, 1.5, -2), 1.0, flat), 0.8, b.isotropic(b.solid((1.0, 0.6, 0.2))))
+    return b.list([ground, b.bvh(balls + [wall, lamp]), puff, mirror, slab, b.sphere((-3, 2, -3), 0.7, red)])
+
+
+@pytest.mark.gpu
+def test_gpu_fast_traversal_with_unbounded_planes_equals_counting_kernel_and_oracle(rl, oracle):
+    import torch
+    world = rl.World.build(_planes_scene)
+    out16 = (rl.api.C.c_uint64 * 16)()
+    rl.api.render_lib().rl_debug_host_structures.argtypes = [rl.api.C.c_void_p, rl.api.C.c_void_p]
+    assert rl.api.render_lib().rl_debug_host_structures(world.desc, out16) == 0 and (out16[0] & 2)
+    assert out16[14] == 2 and out16[15] == 0x0012  # puff: a sphere behind a box node; slab: general shape, no box node
+    for seed, depth in ((3, 1), (4, 12)):
+        p = rl.CameraParams(aspect_ratio=1.5, image_width=90, samples_per_pixel=16, max_depth=depth, vfov=60.0, lookfrom=(0.5, 1.5, 9), lookat=(0, 0.3, 0),
+                            background=(0.4, 0.5, 0.8), seed=seed)
+        cam = rl.Camera(p)
+        gs, cs = {}, {}
+        counting = cam.render(world, stats=gs).data
+        buf = torch.full((cam.c.image_height, cam.c.image_width, 3), float("nan"), dtype=torch.float64, device="cuda:0")
+        cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        st = rl.api.render_status(world)
+        fast = buf.cpu().numpy()
+        assert np.array_equal(fast.view(np.uint64), counting.view(np.uint64)), (depth, int((fast != counting).any(axis=2).sum()))
+        assert st["rays"] == gs["rays"] and st["flagged"] == gs["flagged"]
+        cpu = oracle.rtiow_render(world.desc, cam.c, stats=cs)
+        for k in ("rays", "node_tests", "sphere_tests", "planar_tests", "instance_enters", "rng_words", "flagged"):
+            assert gs[k] == cs[k], (k, gs[k], cs[k])
+        assert np.abs(counting - cpu).max() <= 1e-9 * max(1.0, np.abs(cpu).max())
