@@ -14,6 +14,8 @@
 // tests/test_gpu_timed_kernels.py compares the two kernels bit for bit; bench.py does so on the full frame after every run.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -681,6 +683,34 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
     for (size_t sg = 0; sg < n_seg; sg++)
       if (broots[sg] != NONE && !(broots[sg] & FASTG_LEAF)) out.seg_roots[sg] = fold(broots[sg]);
   }
+  // ---- the top of the first tree in breadth-first order at the front of the array (FASTG_TOP_NODES of them: rl_rtiow_fastgen.h stages them in LDS)
+  out.top_nodes = 0;
+  if (out.seg_roots[0] != NONE && !(out.seg_roots[0] & FASTG_LEAF)) {
+    std::vector<uint32_t> order;  // old ids, new order
+    std::vector<uint32_t> newid(out.qnodes.size(), NONE);
+    order.push_back(out.seg_roots[0]);
+    newid[out.seg_roots[0]] = 0;
+    for (size_t h = 0; h < order.size() && order.size() < FASTG_TOP_NODES; h++)
+      for (int k = 0; k < 4; k++) {
+        const uint32_t ch = out.qnodes[order[h]].child[k];
+        if (ch == NONE || (ch & FASTG_LEAF) || order.size() >= FASTG_TOP_NODES) continue;
+        newid[ch] = (uint32_t)order.size();
+        order.push_back(ch);
+      }
+    out.top_nodes = (uint32_t)order.size();
+    for (uint32_t i = 0; i < out.qnodes.size(); i++)
+      if (newid[i] == NONE) newid[i] = (uint32_t)order.size(), order.push_back(i);
+    std::vector<FastNodeQ> moved(out.qnodes.size());
+    for (size_t i = 0; i < order.size(); i++) {
+      FastNodeQ q = out.qnodes[order[i]];
+      for (int k = 0; k < 4; k++)
+        if (q.child[k] != NONE && !(q.child[k] & FASTG_LEAF)) q.child[k] = newid[q.child[k]];
+      moved[i] = q;
+    }
+    out.qnodes.swap(moved);
+    for (uint32_t &r : out.seg_roots)
+      if (r != NONE && !(r & FASTG_LEAF)) r = newid[r];
+  }
   out.qroot = out.seg_roots[0];
   // ---- stages of a ray's walk: segment 0's tree, medium 0, segment 1's tree, ...; a medium is a one-child node whose box is the union of
   // its boundary parts' padded boxes (a boundary without bounded parts can never be hit: no stage)
@@ -805,6 +835,7 @@ bool build_fast_general(const rl_rtiow_scene_desc &d, const RtiowProgram &rt, Fa
   for (int ax = 0; ax < 3; ax++) out.center[ax] = (float)c[ax];
   out.r_safe = round_down(r_safe * 0.999 - 1e-6 * cabs);  // the device compares binary32 roundings of o and centre
   out.ok = out.r_safe > 0.0f;
+  if (std::getenv("RL_DEBUG_FG")) std::fprintf(stderr, "[fastg] items %zu centre (%g %g %g) r_safe %g radius %g pad_k %g\n", n, c[0], c[1], c[2], (double)out.r_safe, (double)out.radius, (double)out.pad_k);
   return out.ok;
 }
 

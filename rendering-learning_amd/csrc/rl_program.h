@@ -174,6 +174,7 @@ struct alignas(16) FastItem {
 // The items are therefore cut into SEGMENTS at the media (segment s = the primitive occurrences between medium s - 1 and medium s in
 // program order), each segment has its own tree, and a ray walks tree 0, evaluates medium 0, walks tree 1, ... (rl_rtiow_fastgen.h MEDIA).
 static const uint32_t FASTG_MEDIUM = 0x40000000u;  // entry / `best`: a medium (low bits: its index in FastGeneral::media)
+static const uint32_t FASTG_TOP_NODES = 512;  // the breadth-first prefix of the node array; a launch stages as many of them as its LDS has room for
 struct FastMedium {
   uint32_t pc;     // its OP_MEDIUM_BEGIN
   uint32_t chain;  // pc of the innermost PUSH op around it (NONE: world space)
@@ -199,6 +200,7 @@ struct FastGeneral {
   // what a ray walks, in order: per segment its unbounded Planes (leaf entries: every ray tests them) and its tree, then the medium behind
   // it (a one-child box node, or the medium's leaf entry itself when its boundary holds a Plane); empty stages are left out
   std::vector<uint32_t> stage_roots;
+  uint32_t top_nodes = 0;  // qnodes[0 .. top_nodes) = the top of segment 0's tree in breadth-first order (what the kernels stage in LDS)
   std::vector<uint32_t> media_stage;  // index of medium k's stage in stage_roots (NONE: the boundary has no parts)
   float center[3] = {0, 0, 0};  // rays whose origin is within r_safe (Euclidean) of `center` may use the structure; the rest
   float r_safe = 0;             // walk it with grown boxes and without pruning by the closest hit (rl_rtiow_fastgen.h start_ray)

@@ -48,6 +48,8 @@ struct Switches {
   bool coop_small = true;        // RL_COOP=0: small frames through the wave-scheduled kernel instead of the cooperative one
   double steal_max_fill = 3.0;   // RL_STEAL=<pixels per lane> (0 = off): work stealing on small shards
   bool fast_traversal = true;    // RL_FAST=0: counter-free renders use the reference-order kernels too
+  unsigned fastg_top_max = 512;  // RL_FASTG_TOP=<n > 1>: at most n nodes
+  bool fastg_top = true;         // RL_FASTG_TOP=0: the fast general kernel reads every node through L1 (A/B of the LDS tree top)
   bool tune_set = false;         // RL_TUNE="steps,floor16[,batch,fill]"
   unsigned tune[4] = {24, 6, 24, 40};
   unsigned blocks_cap = 0;       // RL_BLOCKS
@@ -87,6 +89,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_GENERAL_REGS")) w.general_regs = std::atoi(v);
   w.fastg512 = std::getenv("RL_FASTG512") != nullptr;
   if (const char *v = std::getenv("RL_FASTG_OCTO")) w.fastg_octo = std::atoi(v);
+  if (const char *v = std::getenv("RL_FASTG_TOP")) w.fastg_top = std::atoi(v) != 0, w.fastg_top_max = (unsigned)std::atoi(v) > 1u ? (unsigned)std::atoi(v) : 512u;
   if (const char *v = std::getenv("RL_GENERAL_NT")) w.general_nt = std::atoi(v);
   if (const char *v = std::getenv("RL_THIN")) w.thin_permille = std::atof(v);
   if (const char *v = std::getenv("RL_PRIO")) w.prio_permille = std::atof(v);
@@ -755,6 +758,7 @@ static int fill_rtiow_params(const rl_scene *scene, const rl_rtiow_camera *cam, 
   P.fg_onodes = scene->d_fg_onodes, P.fg_oroot = H.fg.oroot;
 #endif
   P.fg_seg_roots = scene->d_fg_seg_roots, P.fg_media = scene->d_fg_media, P.fg_n_seg = (uint32_t)H.fg.stage_roots.size();
+  P.fg_top = 0;  // (set by the launch that stages it: fastg_lds)
   P.fg_center[0] = H.fg.center[0], P.fg_center[1] = H.fg.center[1], P.fg_center[2] = H.fg.center[2];
   P.fg_radius = H.fg.radius, P.fg_pad_k = H.fg.pad_k;
   P.cam = *cam;
@@ -948,6 +952,13 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     HIP_TRY(hipGetLastError());
     return RL_OK;
   };
+  // LDS of a fast general launch: rings + stacks, and the tree's top in what is left (P.fg_top nodes, breadth first: FastGeneral::top_nodes)
+  auto fastg_lds = [&](int NT, int SD) -> size_t {
+    const size_t base = (size_t)NT * (16 * sizeof(unsigned long long) + (size_t)SD * sizeof(uint32_t));
+    const size_t room = g_lds_max > base ? (g_lds_max - base) / sizeof(FastNodeQ) : 0;
+    P.fg_top = g_sw.fastg_top ? (uint32_t)std::min<size_t>(H.fg.top_nodes, std::min<size_t>(room, g_sw.fastg_top_max)) : 0u;
+    return base + (size_t)P.fg_top * sizeof(FastNodeQ);
+  };
   auto launch_variant = [&]() -> int {
     int rc;
     if (variant == 2) {
@@ -972,21 +983,22 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       bool trans = rt.has_noise || rt.has_sphere_uv;
       if (H.fg.stage_roots.size() > 1) {  // several stages (media, unbounded Planes): the boundary walks and the Isotropic phase function need the 256-register budget
         constexpr int NT = 512, SD = 40;
-        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        size_t rb = fastg_lds(NT, SD);
         rc = trans ? launch_ptr(rtiow_fast_general_kernel<NT, SD, true, false, true>, NT, rb) : launch_ptr(rtiow_fast_general_kernel<NT, SD, false, false, true>, NT, rb);
       } else if (trans) {  // 512 lanes per CU (the transcendental texture code needs 256 VGPRs), 40-entry stacks
         constexpr int NT = 512, SD = 40;
-        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        size_t rb = fastg_lds(NT, SD);
         rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, true>, NT, rb);
 #ifdef RL_EXPERIMENTAL
       } else if (g_sw.fastg512) {
         constexpr int NT = 512, SD = 40;
-        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        size_t rb = fastg_lds(NT, SD);
         rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, false>, NT, rb);
 #endif
-      } else {  // 768 lanes per CU (3 waves per SIMD hide more of the node-fetch latency), 20-entry stacks: 208 B of LDS per lane
+      } else {  // 768 lanes per CU (3 waves per SIMD hide more of the node-fetch latency), 20-entry stacks: 208 B of LDS per lane, and the
+        // 4 KB that leaves of 160 KB hold the top 32 nodes of the tree (cfg 4 +1.1 %, cfg 5 +0.4 %; 128 nodes with 16-entry stacks: the same)
         constexpr int NT = 768, SD = 20;
-        size_t rb = (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t));
+        size_t rb = fastg_lds(NT, SD);
 #ifdef RL_EXPERIMENTAL  // eight-wide quantised nodes (FastNodeO): cow scene 6.1 -> 3.8 steps per ray but -3.5 %, cfg 5 16.5 -> 13.9 steps, +10 % LEAF visits, -15 %
         if (!H.fg.onodes.empty() && g_sw.fastg_octo != 0) rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, false, true>, NT, rb);
         else

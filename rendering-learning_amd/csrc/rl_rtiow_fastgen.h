@@ -183,8 +183,14 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;                                   // [16][NT]
   uint32_t *s_stack = (uint32_t *)(smem + (size_t)16 * NT * sizeof(unsigned long long));  // [SD][NT]
+  uint4 *s_top = (uint4 *)(smem + (size_t)NT * (16 * sizeof(unsigned long long) + SD * sizeof(uint32_t)));  // [fg_top] FastNodeQ: the tree's top
   const DevOp *ops = P.ops;
   const FastNodeQ *nodes = P.fg_nodes;
+  const uint32_t top = OCTO ? 0u : P.fg_top;
+  if (top) {
+    for (uint32_t i = (uint32_t)tid; i < top * 8u; i += (uint32_t)NT) s_top[i] = ((const uint4 *)nodes)[i];
+    __syncthreads();
+  }
   const FastItem *items = P.fg_items;
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
@@ -254,6 +260,14 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
     grow = 0.0f;
 #ifdef RL_FASTG_VERIFY
     c_unsafe += unsafe ? 1u : 0u;
+    if (unsafe && P.tune[2] == 77u) {  // RL_TUNE=a,b,77: log the first far-origin rays instead of mismatches (what starts out there?)
+      unsigned k = atomicAdd(&g_vcount, 1u);
+      if (k < 64) {
+        double *L = g_vlog[k];
+        L[0] = wo.x, L[1] = wo.y, L[2] = wo.z, L[3] = wd.x, L[4] = wd.y, L[5] = wd.z, L[6] = time, L[7] = (double)far2;
+        L[8] = (double)depth, L[9] = (double)P.fg_rsafe2, L[10] = (double)px, L[11] = 9.0;
+      }
+    }
 #endif
     if (unsafe) {  // pad(L) = fg_pad_k * L^2 in world units (rl_fast_bvh.cpp), L = distance to the centre + the scene's radius; in units of t: / min |d_k|
       float L = sqrtf(far2) + P.fg_radius;
@@ -388,7 +402,8 @@ __global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParam
               if (sp < (uint32_t)SD) s_stack[(size_t)sp * NT + tid] = e, sp++;
               else amb = true;  // more pending children than the stack holds: the reference's order decides
             };
-            const Float4 *nd = (const Float4 *)(nodes + pc);
+            // the tree's top (breadth first, FastGeneral::top_nodes) sits in LDS, the rest comes through L1 / L2 / Infinity Cache
+            const Float4 *nd = pc < top ? (const Float4 *)(s_top + pc * 8u) : (const Float4 *)(nodes + pc);
             // Measured and dropped (round 3, RL_TUNE experiment bits): the node's first 16 bytes alone, then an s_waitcnt, then the other six
             // loads (so that they find the line in L1 instead of pending): cfg 5 -2.5 %, cfg 4 -1 %; the same 112 bytes as fourteen 8-byte
             // loads (twice the L1 accesses): cfg 5 -9.5 %, cfg 4 -3.5 % — the L1 access rate is a second-order cost, not the bound.

@@ -72,6 +72,7 @@ struct RtiowParams {
   const uint32_t *fg_seg_roots;  // rl_rtiow_fastgen.h MEDIA: root entry of every program segment (FastGeneral::seg_roots)
   const FastMedium *fg_media;    // ... and the media between them
   uint32_t fg_n_seg;
+  uint32_t fg_top;  // the first fg_top nodes of fg_nodes (the tree's top, breadth first) are copied into LDS by every workgroup (0: none)
 };
 
 // ---------------------------------------------------------------- ChaCha8
