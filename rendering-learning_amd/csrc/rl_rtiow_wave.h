@@ -28,7 +28,10 @@ namespace rl {
 
 // ST_SHADE2 (fast traversal only): the specular half of SHADE — Metal and Dielectric hits — so that the many Lambertian / miss lanes
 // do not walk through normalize(), Schlick and refract() code they never need
-enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6, ST_PARK = 7 };
+#ifndef RL_SPLIT_LEAF
+#define RL_SPLIT_LEAF false
+#endif
+enum : uint32_t { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_FILL = 3, ST_DONE = 4, ST_LEAF = 5, ST_SHADE2 = 6, ST_PARK = 7, ST_LEAF2 = 8 };
 // The latency modes of DESIGN.md §6 (RL_THIN: thin tiles, RL_PRIO: wave priority) — measured, no gain — are compiled into the
 // experimental library only (make exp); the product kernel carries none of their code.
 #ifdef RL_EXPERIMENTAL
@@ -262,6 +265,17 @@ __device__ __forceinline__ bool fast_hit_is_order_sensitive(D3 oc, D3 d, double 
   return grazing || pole || !(eps * (double)dmax < 5e-5 * r);
 }
 
+// the first lines of Sphere::hit (sphere.rs:32-47): true when the discriminant is negative (same arithmetic as fast_sphere_hit below)
+__device__ __forceinline__ bool fast_sphere_misses(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time) {
+  D3 c0 = ld3(s.c0);
+  D3 center = (payload & SPH_MOVING) ? c0 + ld3(s.dc) * time : c0;
+  D3 oc = o - center;
+  double a = len2(d);
+  double half_b = dot(oc, d);
+  double c = len2(oc) - s.r2;
+  return half_b * half_b - a * c < 0.0;
+}
+
 // Sphere::hit (sphere.rs:32-75) with the acceptance window widened by the tie band; same arithmetic, same root values.
 __device__ __forceinline__ void fast_sphere_hit(const DevSphere &s, uint32_t payload, D3 o, D3 d, double time, float oimax, double &closest, uint32_t &hit_prim,
                                                 bool &amb) {
@@ -462,6 +476,11 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   // measured and lost (kept switchable): a separate block for Metal / Dielectric hits shortens SHADE (35.7 % -> 23.3 + 5.2 % of the
   // wave time) but a sixth state thins every other block (TRAV population 21.2 -> 18.5, LEAF 30.8 -> 27.0): 6.14 -> 5.52 Grays/s
   constexpr bool SPLIT_SHADE = false;
+  // SPLIT_LEAF (fast traversal): LEAF only evaluates the discriminant — a sphere whose box the ray passed but which it misses (about half of
+  // the visits) sends the lane straight back to TRAV — and the roots, the tie band and the order checks of an actual hit run in LEAF2.
+  // Measured (round 3, -DRL_SPLIT_LEAF=true): 6709 -> 5907 Mrays/s, 1/8 shard 173 -> 205 ms — like SPLIT_SHADE, one more scheduling class
+  // costs more in population per block than the shorter blocks give back (tools/sched.py: LEAF is 32 % of the time at 35 lanes per block)
+  constexpr bool SPLIT_LEAF = RL_SPLIT_LEAF;
   auto shade_state = [&]() -> uint32_t {  // where a finished traversal is shaded
     if (!SPLIT_SHADE || LDS_SCENE != 4 || hit_prim == NONE) return ST_SHADE;
     const uint32_t si = hit_prim & SPH_INDEX;
@@ -603,13 +622,14 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     int n_gen = __popcll(__ballot(state == ST_GEN));
     int n_leaf = __popcll(__ballot(state == ST_LEAF));
     int n_shade2 = SPLIT_SHADE && LDS_SCENE == 4 ? __popcll(__ballot(state == ST_SHADE2)) : 0;
+    int n_leaf2 = SPLIT_LEAF && LDS_SCENE == 4 ? __popcll(__ballot(state == ST_LEAF2)) : 0;
     if (LATENCY_MODES && LDS_SCENE == 4 && P.thin_tiles != 0u) {  // parked lanes wake up when no lane of the wave holds a thin pixel any more
       if (__ballot(state == ST_PARK) != 0ull && __ballot(have_pixel && thin_pix) == 0ull) {
         if (state == ST_PARK) state = ST_GEN;
         n_gen = __popcll(__ballot(state == ST_GEN));
       }
     }
-    if ((n_trav | n_shade | n_fill | n_gen | n_leaf | n_shade2) == 0) break;
+    if ((n_trav | n_shade | n_fill | n_gen | n_leaf | n_shade2 | n_leaf2) == 0) break;
     uint32_t pick = ST_TRAV;
     int best = n_trav;
     if (n_leaf > best) pick = ST_LEAF, best = n_leaf;
@@ -617,6 +637,7 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
     if (n_fill > best) pick = ST_FILL, best = n_fill;
     if (n_gen > best) pick = ST_GEN, best = n_gen;
     if (SPLIT_SHADE && LDS_SCENE == 4 && n_shade2 > best) pick = ST_SHADE2, best = n_shade2;
+    if (SPLIT_LEAF && LDS_SCENE == 4 && n_leaf2 > best) pick = ST_LEAF2, best = n_leaf2;
 
     unsigned long long t_begin = 0;
     if (STATS) {  // debug (tools/sched.py): block executions, lanes served and shader cycles per state, per wave
@@ -711,8 +732,13 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
             const uint32_t sidx = pc - P.n_fast_inner;
             const uint32_t payload = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u);
             if (STATS) c_sph++;
-            fast_sphere_hit(spheres[sidx], payload, o, d, time, ra32.oimax(), closest, hit_prim, amb);
-            fast_go(fast_pop());
+            if (SPLIT_LEAF) {
+              if (fast_sphere_misses(spheres[sidx], payload, o, d, time)) fast_go(fast_pop());
+              else state = ST_LEAF2;
+            } else {
+              fast_sphere_hit(spheres[sidx], payload, o, d, time, ra32.oimax(), closest, hit_prim, amb);
+              fast_go(fast_pop());
+            }
           }
         }
       } else if (state == ST_LEAF) {  // Sphere::hit for the 1-2 spheres of a BVH leaf / one list item, in stored order
@@ -735,6 +761,13 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
         closest = h.t, hit_prim = h.prim;
         pc = w & 0x1FFFFFFFu;
         state = w >> 29;
+      }
+    } else if (SPLIT_LEAF && LDS_SCENE == 4 && pick == ST_LEAF2) {
+      if (state == ST_LEAF2) {
+        const uint32_t sidx = pc - P.n_fast_inner;
+        const uint32_t payload = sidx | (((s_bits[sidx >> 5] >> (sidx & 31u)) & 1u) ? SPH_MOVING : 0u);
+        fast_sphere_hit(spheres[sidx], payload, o, d, time, ra32.oimax(), closest, hit_prim, amb);
+        fast_go(fast_pop());
       }
     } else if (pick == ST_FILL) {
       if (state == ST_FILL) {
