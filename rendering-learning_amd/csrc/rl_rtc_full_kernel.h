@@ -405,7 +405,7 @@ struct Pending {
 
 // NT threads per workgroup; REGS_FOR = the workgroup size the register budget is computed for (512 -> 256 registers, two waves per SIMD)
 template <int NT, int REGS_FOR>
-__global__ void __launch_bounds__(REGS_FOR) rtc_full_kernel(RtcFullParams F) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(REGS_FOR) rtc_full_kernel(RtcFullParams F) {
   const RtcParams &P = F.R;
   const int tid = threadIdx.x;
   const DevOp *ops = P.ops;

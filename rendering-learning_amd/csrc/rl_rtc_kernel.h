@@ -11,6 +11,12 @@
 // materials are rejected with RL_E_UNSUPPORTED at scene creation).
 // One lane per pixel; the n x n anti-aliasing grid is summed in the reference's order.
 #pragma once
+#ifndef RL_KERNEL_ALIGN
+// Every big kernel starts on a 64 KB boundary of the code object.  Measured (round 3): the stealing instantiation of rtiow_wave_kernel (77 KB of
+// code: main loop + cooperative body, more than the 64 KB instruction cache two CUs share) ran the 1/8 shard in 174 or in 189 ms depending on
+// nothing but where the linker happened to put it (0x...ad00 against 0x...d600 after unrelated kernels grew); aligned, the placement is fixed.
+#define RL_KERNEL_ALIGN __attribute__((aligned(65536)))
+#endif
 #include "rl_device.h"
 
 namespace rl {
@@ -243,7 +249,7 @@ __device__ __forceinline__ double rtc_traverse(const RtcParams &P, const DevOp *
 // REGS_FOR: the workgroup size the register budget is computed for (NT: one wave per SIMD and up to 512 registers, 2 NT / 3 NT / 4 NT: the
 // budget of two / three / four waves per SIMD)
 template <int NT, bool LDS_SCENE, int REGS_FOR = NT>
-__global__ void __launch_bounds__(REGS_FOR) rtc_kernel(RtcParams P) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(REGS_FOR) rtc_kernel(RtcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const DevOp *ops = P.ops;

@@ -308,7 +308,7 @@ struct CoopLinearCand {  // candidate list of a wave: max_cand consecutive words
 // NW waves per workgroup; LDS: [8][NW * 64] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NW][max_cand] u32.
 // REGS_FOR: the workgroup size the register budget is computed for (1024: 128 VGPRs, four waves per SIMD)
 template <int NW, bool BOXES_IN_REGS, int REGS_FOR>
-__global__ void __launch_bounds__(REGS_FOR) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(REGS_FOR) rtiow_coop_kernel(RtiowParams P, CoopParams C) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
   unsigned long long *s_rng = (unsigned long long *)smem;

@@ -175,7 +175,7 @@ __device__ __forceinline__ void fastg_sphere_hit(const DevSphere &s, uint32_t pa
 // never decide whether it draws: a ray that misses a box inside [t_min, closest] has an empty stretch inside the boundary, too.)  An
 // order-sensitive ray rewinds the ring to the word position the ray started at and is re-traced by the reference's fold WITH its media.
 template <int NT, int SD, bool TRANS, bool OCTO = false, bool MEDIA = false>
-__global__ void __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParams *__restrict__ Pp) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_fast_general_kernel(const RtiowParams *__restrict__ Pp) {
   // the parameter block is read from memory where it is needed (uniform addresses: scalar loads through the constant cache) instead of
   // arriving by value: by value every field that is live anywhere is loaded at kernel entry and pins SGPRs for the kernel's life time
   const RtiowParams &P = *Pp;

@@ -268,7 +268,7 @@ __device__ __forceinline__ void general_trace(const RtiowParams &P, const DevOp 
 
 // REGS_FOR: the workgroup size the register budget is computed for (NT: one wave per SIMD, 2 NT: two, 3 NT: three)
 template <int NT, bool STATS, int REGS_FOR = NT>
-__global__ void __launch_bounds__(REGS_FOR) rtiow_general_kernel(RtiowParams P) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(REGS_FOR) rtiow_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;  // [8][NT]

@@ -8,6 +8,12 @@
 // next from a global counter when done (persistent lanes).  The scene program (rl_program.h) and the
 // sphere table are staged in LDS once per workgroup; traversal is stackless.
 #pragma once
+#ifndef RL_KERNEL_ALIGN
+// Every big kernel starts on a 64 KB boundary of the code object.  Measured (round 3): the stealing instantiation of rtiow_wave_kernel (77 KB of
+// code: main loop + cooperative body, more than the 64 KB instruction cache two CUs share) ran the 1/8 shard in 174 or in 189 ms depending on
+// nothing but where the linker happened to put it (0x...ad00 against 0x...d600 after unrelated kernels grew); aligned, the placement is fixed.
+#define RL_KERNEL_ALIGN __attribute__((aligned(65536)))
+#endif
 #include "rl_device.h"
 
 namespace rl {
@@ -85,13 +91,19 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin
   c += d, b ^= c, b = rotl32(b, 7);
 
 // Generates block (key, ctr, stream) and stores its 16 words as 8 u64 into the lane's LDS column.
-template <int NT>
+// ROLLED: the four double rounds as a loop (a quarter of the code).  A block is ~420 instructions (2 KB) unrolled, and inlined at every
+// gen_f64 call site the copies made up half of the wave kernels' code — 37 of the 77 KB of the stealing instantiation, more than the 64 KB
+// instruction cache two CUs share.  The wave-scheduled kernels (rl_rtiow_wave.h Ring) use the rolled form everywhere: main kernel 7292 ->
+// 4728 instructions and no spills left, stealing instantiation 13943 -> 8986 and 38 -> 6 spilled VGPRs; 6709 -> 6770 Mrays/s, 1/8 shard
+// 174 -> 163 ms.  The cooperative one-wave-per-pixel body keeps the unrolled form: there a block is on the pixel's critical path.
+// (A real function call for the rare mid-SHADE refill was measured too: its register convention spills 36 more VGPRs in the main loop, 4940 Mrays/s.)
+template <int NT, bool ROLLED = false>
 __device__ __forceinline__ void chacha8_block_to_lds(const uint32_t *key, uint32_t ctr_lo, uint64_t stream, unsigned long long *s_rng, int tid) {
   const uint32_t c0 = 0x61707865u, c1 = 0x3320646eu, c2 = 0x79622d32u, c3 = 0x6b206574u;
   uint32_t s12 = ctr_lo, s13 = 0u, s14 = (uint32_t)stream, s15 = (uint32_t)(stream >> 32);
   uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6],
            x11 = key[7], x12 = s12, x13 = s13, x14 = s14, x15 = s15;
-#pragma unroll
+#pragma unroll(ROLLED ? 1 : 4)
   for (int r = 0; r < 4; r++) {
     RL_QR(x0, x4, x8, x12) RL_QR(x1, x5, x9, x13) RL_QR(x2, x6, x10, x14) RL_QR(x3, x7, x11, x15)
     RL_QR(x0, x5, x10, x15) RL_QR(x1, x6, x11, x12) RL_QR(x2, x7, x8, x13) RL_QR(x3, x4, x9, x14)

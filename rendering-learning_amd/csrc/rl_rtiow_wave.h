@@ -41,7 +41,9 @@ static constexpr bool LATENCY_MODES = false;
 #endif
 
 // two-block ChaCha ring in LDS: 16 u64 slots per lane, slot-major ([slot][lane]) => conflict-free
-template <int NT>
+// ROLL_HOT: also the block generations on the hot paths (stream reset, FILL) use the rolled block function (rl_rtiow_kernel.h
+// chacha8_block_to_lds<NT, true>); the refill in the middle of a SHADE block (rare: long rejection streaks) always does.
+template <int NT, bool ROLL_HOT = true>
 struct Ring {
   const uint32_t *key;
   unsigned long long *s_rng;  // [16][NT]
@@ -51,12 +53,12 @@ struct Ring {
   uint32_t blk_lo;  // lowest resident block counter
   uint32_t nres;    // resident blocks: blk_lo .. blk_lo+nres-1 (0..2); block c lives in half (c & 1)
 
-  __device__ __forceinline__ void gen_block(uint32_t c) { chacha8_block_to_lds<NT>(key, c, stream, s_rng + (size_t)(c & 1u) * 8 * NT, tid); }
+  __device__ __forceinline__ void gen_block(uint32_t c) { chacha8_block_to_lds<NT, ROLL_HOT>(key, c, stream, s_rng + (size_t)(c & 1u) * 8 * NT, tid); }
   __device__ __forceinline__ void reset_stream(uint64_t s) {  // set_stream keeps pos; both resident blocks become stale
     stream = s;
     blk_lo = pos >> 4;
-    gen_block(blk_lo);
-    gen_block(blk_lo + 1);
+#pragma unroll 1
+    for (uint32_t k = 0; k < 2u; k++) gen_block(blk_lo + k);  // (rolled: one copy of the block function's 2 KB, not two)
     nres = 2;
   }
   __device__ __forceinline__ bool low() const { return (pos >> 4) >= blk_lo + nres - 1u; }  // reading from the newest block
@@ -68,7 +70,12 @@ struct Ring {
   }
   __device__ __forceinline__ uint64_t next_u64() {
     uint32_t c = pos >> 4;
-    if (c - blk_lo >= nres) top_up();  // rare inline path (long rejection streaks)
+    if (c - blk_lo >= nres) {  // rare inline path (long rejection streaks): always the rolled block function, a quarter of the code per call site
+      const uint32_t nc = blk_lo + nres;
+      chacha8_block_to_lds<NT, true>(key, nc, stream, s_rng + (size_t)(nc & 1u) * 8 * NT, tid);
+      if (nres == 2) blk_lo++;
+      else nres++;
+    }
     uint64_t v = s_rng[((size_t)(c & 1u) * 8 + ((pos & 15u) >> 1)) * NT + tid];
     pos += 2;
     return v;
@@ -365,7 +372,7 @@ __device__ __forceinline__ void rtiow_steal_loop(const RtiowParams &P, unsigned 
 // (6625 against 6707 Mrays/s; the work-stealing instantiation 212 against 178 ms on the 1/8 shard): the v_readlane restores sit in block
 // preambles, the scalar loads would sit in the blocks.)
 template <int NT, int LDS_SCENE, bool STATS, bool STEAL = false>
-__global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   // LDS layout: [linked ops][spheres][ChaCha rings 16 x NT u64]; with the scene in HBM the rings start at 0
@@ -444,7 +451,8 @@ __global__ void __launch_bounds__(NT) rtiow_wave_kernel(RtiowParams P) {
   const double INF = __longlong_as_double(0x7FF0000000000000ll);
 
   // ---- per-lane persistent state
-  Ring<NT> rng{P.key, s_rng, tid, 0ull, 0u, 0u, 0u};
+  // (the stealing instantiation keeps the unrolled block function on its hot paths: measured, 1/8 and 1/4 shard 170 / 263 ms against 163 / 283 rolled)
+  Ring<NT, !STEAL> rng{P.key, s_rng, tid, 0ull, 0u, 0u, 0u};
   uint32_t state = ST_GEN;
   uint32_t px = 0, pr = 0, n = spp;  // n == spp: no pixel owned yet
   uint32_t ptile = 0, pix_rays = 0;

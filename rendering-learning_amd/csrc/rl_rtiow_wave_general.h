@@ -26,7 +26,7 @@ enum : uint32_t { ST_XF = 6 };
 // filtered test is derived for [1e-10, closest]).  Media do not nest (rl_program.cpp).
 static const int MEDIA_SAVE_WORDS = 12;  // parked Rec: t, p, normal, u, v, w, {mat, pc}, flags
 template <int NT, bool TRANS, bool STATS, bool MEDIA = false>
-__global__ void __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
+__global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_general_kernel(RtiowParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   unsigned long long *s_rng = (unsigned long long *)smem;  // [16][NT]
