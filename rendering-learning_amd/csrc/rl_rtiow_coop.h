@@ -36,12 +36,66 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 // LDS: [8][NT] u64 RNG blocks (one per lane, all lanes of a wave hold the same) + [NT / 64][max_cand] u32 candidate lists.
 // BOXES_IN_REGS: lane l keeps the leaf boxes of spheres l, l + 64, ... l + 448 in 48 registers (scenes of up to 512 spheres) — the
 // lowest latency per ray; without it the boxes come from L2 every ray and the kernel fits the register budget of four waves per SIMD
+// The pixel's ChaCha8 words for a whole wave that works on ONE pixel: every lane generates a DIFFERENT block of the current stream — lane l the
+// block (base + l) — into its own column of the [8][NT] u64 block rows, so one pass of the block function (the same ~420 instructions that used
+// to produce 16 words, identically in all 64 lanes) yields 1024 consecutive words: more than a sample ever draws (a fresh stream per sample,
+// camera.rs:167-170, the word position runs on).  A draw is one uniform LDS read from the column of the block that holds the word.
+template <int NT>
+struct WaveRng {
+  const uint32_t *key;
+  unsigned long long *s_rng;  // [8][NT]
+  int tid;
+  uint64_t stream;
+  uint32_t pos;   // u32 word position since the pixel started
+  uint32_t base;  // block counter held by lane 0 of the wave (blocks base .. base + 63 are resident); 0xFFFFFFFF = none
+  template <bool ROLLED>
+  __device__ __forceinline__ void fill(uint32_t b) {  // make blocks b .. b + 63 of `stream` resident
+    __builtin_amdgcn_wave_barrier();  // every lane has finished reading the previous blocks
+    chacha8_block_to_lds<NT, ROLLED>(key, b + (uint32_t)(tid & 63), stream, s_rng, tid);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    base = b;
+  }
+  __device__ __forceinline__ void set_stream(uint64_t s) {  // (the one unrolled copy of the block function: once per sample)
+    stream = s;
+    fill<false>(pos >> 4);
+  }
+  __device__ __forceinline__ uint64_t next_u64() {
+    const uint32_t b = pos >> 4;
+    if (b - base >= 64u) fill<true>(b);  // more than 1024 words in one sample (or none resident yet): the rolled form, a quarter of the code per call site
+    const uint64_t v = s_rng[(size_t)((pos & 15u) >> 1) * NT + (size_t)((tid & ~63) + (int)(b - base))];
+    pos += 2;
+    return v;
+  }
+  __device__ __forceinline__ double gen_f64() { return (double)(next_u64() >> 11) * 0x1.0p-53; }
+  __device__ __forceinline__ double uniform_m1_1() {
+    double v = __longlong_as_double((long long)((next_u64() >> 12) | 0x3FF0000000000000ull));
+    return (v - 1.0) * 2.0 + (-1.0);
+  }
+  __device__ __forceinline__ D3 unit_sphere() {  // rand_distr 0.4.3 UnitSphere (Marsaglia 1972): reject s >= 1
+    for (;;) {
+      double x1 = uniform_m1_1(), x2 = uniform_m1_1();
+      double s = x1 * x1 + x2 * x2;
+      if (s >= 1.0) continue;
+      double f = 2.0 * sqrt(1.0 - s);
+      return D3{x1 * f, x2 * f, 1.0 - 2.0 * s};
+    }
+  }
+  __device__ __forceinline__ void unit_disc(double &a, double &b) {  // rand_distr 0.4.3 UnitDisc: accept s <= 1
+    for (;;) {
+      a = uniform_m1_1();
+      b = uniform_m1_1();
+      if (a * a + b * b <= 1.0) return;
+    }
+  }
+};
+
 template <int NT, bool BOXES_IN_REGS, class Source, class Cand>
 __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const float *leaf_boxes, uint32_t max_cand, unsigned long long *s_rng, Cand cand_at, Source src) {
   const int tid = threadIdx.x, lane = tid & 63;
   const DevOp *ops = P.ops;
   const DevSphere *spheres = P.spheres;
-  RngCtx<NT> rc{P.key, s_rng, tid};
   const rl_rtiow_camera &cam = P.cam;
   const uint32_t W = cam.image_width;
   const uint64_t WH = (uint64_t)cam.image_width * (uint64_t)cam.image_height;
@@ -69,24 +123,23 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const floa
     if (!src.next(P, lane, pix, sum, pos0, n_begin)) break;
     const uint32_t x = pix % W, r = pix / W;
     const uint32_t y = P.row_first + r * P.row_step;
-    Rng rng{0ull, pos0, 0xFFFFFFFFu};
+    WaveRng<NT> rng{P.key, s_rng, tid, 0ull, pos0, 0xFFFFFFFFu};
     for (uint32_t n = n_begin; n < P.sample_end; n++) {
       uint64_t sample_index = (uint64_t)n + P.first_sample;
-      rng.stream = sample_index * WH + (uint64_t)x * (uint64_t)W + (uint64_t)y;  // camera.rs:167-169 (x*W, sic)
-      rng.buf_ctr = 0xFFFFFFFFu;
+      rng.set_stream(sample_index * WH + (uint64_t)x * (uint64_t)W + (uint64_t)y);  // camera.rs:167-169 (x*W, sic)
       D3 pixel_center = (p00 + du * (double)x) + dv * (double)y;
-      double sx = -0.5 + rc.gen_f64(rng);
-      double sy = -0.5 + rc.gen_f64(rng);
+      double sx = -0.5 + rng.gen_f64();
+      double sy = -0.5 + rng.gen_f64();
       D3 pixel_sample = pixel_center + (du * sx + dv * sy);
       D3 o;
       if (cam.defocus_angle <= 0.0) o = lookfrom;
       else {
         double a, b;
-        rc.unit_disc(rng, a, b);
+        rng.unit_disc(a, b);
         o = (lookfrom + ddu * a) + ddv * b;
       }
       D3 d = pixel_sample - o;
-      double time = rc.gen_f64(rng);
+      double time = rng.gen_f64();
       D3 thr = d3(1.0, 1.0, 1.0);
       D3 color = d3(0.0, 0.0, 0.0);
       for (uint32_t depth = cam.max_depth; depth > 0; depth--) {
@@ -216,13 +269,13 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const floa
         uint32_t kind = m.kind;
         D3 nd;
         if (kind == RL_MAT_LAMBERTIAN) {
-          D3 dir = normal + rc.unit_sphere(rng);
+          D3 dir = normal + rng.unit_sphere();
           bool near_zero = approx_eq_eps(dir.x, 0.0, 1e-8) && approx_eq_eps(dir.y, 0.0, 1e-8) && approx_eq_eps(dir.z, 0.0, 1e-8);
           nd = near_zero ? normal : dir;
           thr = thr * texture_value(P, m.texture, 0.0, 0.0, p);
         } else if (kind == RL_MAT_METAL) {
           D3 reflected = d - normal * (2.0 * dot(d, normal));
-          nd = normalize(reflected) + rc.unit_sphere(rng) * m.fuzz;
+          nd = normalize(reflected) + rng.unit_sphere() * m.fuzz;
           if (!(dot(nd, normal) > 0.0)) break;
           thr = thr * ld3(m.albedo);
         } else if (kind == RL_MAT_DIELECTRIC) {
@@ -243,7 +296,7 @@ __device__ __forceinline__ void rtiow_coop_body(const RtiowParams &P, const floa
             double xx = 1.0 - cos_theta;
             double x2 = xx * xx;
             double refl = r0 + (1.0 - r0) * (xx * (x2 * x2));
-            reflect = refl > rc.gen_f64(rng);
+            reflect = refl > rng.gen_f64();
           }
           if (reflect) nd = ud - normal * (2.0 * dot(ud, normal));
           else {
