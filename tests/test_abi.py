@@ -72,3 +72,50 @@ def test_rccl_entry_points_resolve_without_a_device(rl):
     sequence matches the installed <rccl/rccl.h> is a static_assert in rl_multi.hip (a drifted signature fails the build).  The send / recv
     pair itself needs >= 2 physical GPUs and has not executed on hardware yet (README.md / INTEGRATION.md say so)."""
     assert rl.api.render_lib().rl_debug_rccl_loadable() == 1
+
+
+def test_big_kernels_start_on_64k_boundaries_and_the_headline_kernel_does_not_spill():
+    """The gfx950 code objects inside the product library: every kernel larger than 16 KB starts on a 64 KB boundary (RL_KERNEL_ALIGN,
+    csrc/rl_rtiow_kernel.h: where the linker puts a kernel relative to the 64 KB instruction cache two CUs share was measured to be worth
+    8 % on the stealing instantiation), and the timed headline kernel keeps all of its values in registers (spilled VGPRs cost a lone sample
+    chain a scratch round trip per ray: 9.4 against 3.7 us).  Reads the ELF only: no device needed."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not in this image")
+    lib = os.path.join(ROOT, "rendering-learning_amd", "csrc", "librl_render.so")
+    data = open(lib, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    i, big, headline = 0, 0, None
+    while True:
+        i = data.find(magic, i)
+        if i < 0:
+            break
+        ne = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(ne):
+            o, s, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" not in triple or s == 0:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[i + o:i + o + s])
+                f.flush()
+                syms = subprocess.run([readelf, "-s", "--wide", f.name], stdout=subprocess.PIPE, text=True).stdout
+                notes = subprocess.run([readelf, "--notes", f.name], stdout=subprocess.PIPE, text=True).stdout
+            for line in syms.splitlines():
+                p = line.split()
+                if len(p) >= 8 and p[3] == "FUNC" and p[7].startswith("_ZN2rl") and int(p[2]) > 16384:
+                    big += 1
+                    assert int(p[1], 16) % 65536 == 0, (p[7], p[1])
+            m = re.search(r"\.name:\s+_ZN2rl17rtiow_wave_kernelILi1024ELi4ELb0ELb0EEEvNS_11RtiowParamsE\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", notes)
+            if m:
+                headline = int(m.group(1))
+        i += 24
+    assert big >= 10, big
+    assert headline == 0, headline
