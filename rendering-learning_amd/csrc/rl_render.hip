@@ -49,6 +49,7 @@ struct Switches {
   double steal_max_fill = 3.0;   // RL_STEAL=<pixels per lane> (0 = off): work stealing on small shards
   bool fast_traversal = true;    // RL_FAST=0: counter-free renders use the reference-order kernels too
   unsigned fastg_top_max = 512;  // RL_FASTG_TOP=<n > 1>: at most n nodes
+  int fastg_nt256 = -1;          // RL_FASTG_NT256=0|1: never / always the one-wave-per-SIMD form of the fast general kernel (default: by frame size)
   bool fastg_top = true;         // RL_FASTG_TOP=0: the fast general kernel reads every node through L1 (A/B of the LDS tree top)
   bool tune_set = false;         // RL_TUNE="steps,floor16[,batch,fill]"
   unsigned tune[4] = {24, 6, 24, 40};
@@ -89,6 +90,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_GENERAL_REGS")) w.general_regs = std::atoi(v);
   w.fastg512 = std::getenv("RL_FASTG512") != nullptr;
   if (const char *v = std::getenv("RL_FASTG_OCTO")) w.fastg_octo = std::atoi(v);
+  if (const char *v = std::getenv("RL_FASTG_NT256")) w.fastg_nt256 = std::atoi(v) != 0;
   if (const char *v = std::getenv("RL_FASTG_TOP")) w.fastg_top = std::atoi(v) != 0, w.fastg_top_max = (unsigned)std::atoi(v) > 1u ? (unsigned)std::atoi(v) : 512u;
   if (const char *v = std::getenv("RL_GENERAL_NT")) w.general_nt = std::atoi(v);
   if (const char *v = std::getenv("RL_THIN")) w.thin_permille = std::atof(v);
@@ -981,7 +983,19 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
       if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
-      if (H.fg.stage_roots.size() > 1) {  // several stages (media, unbounded Planes): the boundary walks and the Isotropic phase function need the 256-register budget
+      // The flavour with both the media code and the Perlin / acos / atan2 code spills 126 VGPRs at 256 registers.  For small frames (at most
+      // one and a half pixels per lane of the 512-lane form: the frame's time is per-ray latency, and scratch round trips are part of it) it
+      // runs as ONE wave per SIMD with the 512-register budget instead (what would spill lives in AGPRs): final_scene.rs (400x400) 442 ->
+      // 494 ... 513 Mrays/s.  Measured and not taken: the same for the other flavours (quads.rs -17 %, flat_world.rs -24 %, cornell_smoke.rs at
+      // 600x600 -30 %: they spill little, and lose the second wave's latency hiding).  RL_FASTG_NT256=1 / 0 forces it on / off (A/B).
+      const bool media = H.fg.stage_roots.size() > 1;
+      const bool one_wave = trans && media && (g_sw.fastg_nt256 >= 0 ? g_sw.fastg_nt256 != 0 : (uint64_t)nrows * W <= (uint64_t)g_cus * 768u);
+      if (one_wave) {
+        constexpr int NT = 256, SD = 40;
+        size_t rb = fastg_lds(NT, SD);
+        if (rb < 90000) rb = 90000;  // one workgroup per CU
+        rc = launch_ptr(rtiow_fast_general_kernel<NT, SD, true, false, true>, NT, rb);
+      } else if (media) {  // several stages (media, unbounded Planes): the boundary walks and the Isotropic phase function need the 256-register budget
         constexpr int NT = 512, SD = 40;
         size_t rb = fastg_lds(NT, SD);
         rc = trans ? launch_ptr(rtiow_fast_general_kernel<NT, SD, true, false, true>, NT, rb) : launch_ptr(rtiow_fast_general_kernel<NT, SD, false, false, true>, NT, rb);
@@ -1405,6 +1419,7 @@ void rl_debug_set_lpt(int on) { g_sw.lpt = on != 0; }
 void rl_debug_set_coop(int on) { g_sw.coop_small = on != 0; }
 void rl_debug_set_steal(double max_fill) { g_sw.steal_max_fill = max_fill; }
 void rl_debug_set_fast_traversal(int on) { g_sw.fast_traversal = on != 0; }
+void rl_debug_set_fastg_one_wave(int mode) { g_sw.fastg_nt256 = mode; }  // -1: by frame size (default), 0 / 1: never / always the one-wave-per-SIMD form (tests)
 void rl_debug_fast_stats(int on) {  // the instrumented fast kernel <1024, 4, true> exists in the experimental library only
 #ifdef RL_EXPERIMENTAL
   g_fast_debug_stats = on != 0;

@@ -83,3 +83,15 @@ def test_gpu_example_scenes_equal_oracle(rl, oracle, golden, name):
     st = rl.api.render_status(world)
     assert st["rays"] == gs["rays"] and st["flagged"] == 0
     assert np.array_equal(buf.cpu().numpy(), counting), name  # the timed (counter-free) kernel: same bits
+    if name == "final_scene":  # media + Perlin / sphere-UV code: small frames take the one-wave-per-SIMD instantiation (512 registers) — both forms
+        L = rl.api.render_lib()
+        L.rl_debug_set_fastg_one_wave.argtypes = [rl.api.C.c_int]
+        try:
+            for mode in (0, 1):
+                L.rl_debug_set_fastg_one_wave(mode)
+                buf.fill_(float("nan"))
+                cam.render_device(world, buf.data_ptr(), stream=torch.cuda.current_stream(dev).cuda_stream)
+                st = rl.api.render_status(world)
+                assert st["rays"] == gs["rays"] and np.array_equal(buf.cpu().numpy(), counting), mode
+        finally:
+            L.rl_debug_set_fastg_one_wave(-1)
