@@ -28,6 +28,9 @@ namespace rl {
 
 // ST_SHADE2 (fast traversal only): the specular half of SHADE — Metal and Dielectric hits — so that the many Lambertian / miss lanes
 // do not walk through normalize(), Schlick and refract() code they never need
+#ifndef RL_PK_FMA
+#define RL_PK_FMA 0  // the slab test's plane pairs as v_pk_fma_f32: measured 6750 -> 6600 Mrays/s — the broadcast operand pairs cost moves, one VGPR spills
+#endif
 #ifndef RL_SPLIT_LEAF
 #define RL_SPLIT_LEAF false
 #endif
@@ -675,9 +678,17 @@ __global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_kernel(RtiowPar
             const uint32_t w = *(LdsU32 *)(size_t)(pc + 48u);
             const float c32 = (float)closest;
             auto missed = [&](float b0, float b1, float b2, float b3, float b4, float b5, float &tmin) {
+#if RL_PK_FMA  // both planes of a slab in one v_pk_fma_f32 (same IEEE fma per component)
+              typedef float F2 __attribute__((ext_vector_type(2)));
+              const F2 tx = __builtin_elementwise_fma(F2{b0, b1}, F2{ra32.invx, ra32.invx}, F2{-ra32.oix, -ra32.oix});
+              const F2 ty = __builtin_elementwise_fma(F2{b2, b3}, F2{ra32.invy, ra32.invy}, F2{-ra32.oiy, -ra32.oiy});
+              const F2 tz = __builtin_elementwise_fma(F2{b4, b5}, F2{ra32.invz, ra32.invz}, F2{-ra32.oiz, -ra32.oiz});
+              const float t0x = tx.x, t1x = tx.y, t0y = ty.x, t1y = ty.y, t0z = tz.x, t1z = tz.y;
+#else
               float t0x = fmaf(b0, ra32.invx, -ra32.oix), t1x = fmaf(b1, ra32.invx, -ra32.oix);
               float t0y = fmaf(b2, ra32.invy, -ra32.oiy), t1y = fmaf(b3, ra32.invy, -ra32.oiy);
               float t0z = fmaf(b4, ra32.invz, -ra32.oiz), t1z = fmaf(b5, ra32.invz, -ra32.oiz);
+#endif
               tmin = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), 1e-10f);
               float tmax = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), c32);
               float diff = tmax - tmin;
