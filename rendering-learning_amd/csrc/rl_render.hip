@@ -1088,7 +1088,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       size_t rb = (size_t)16 * NT * sizeof(unsigned long long) + fast_bytes;
       // leave a TRAV round when fewer than a quarter of the lanes it started with are still walking (the counting kernels: 3/8): with
       // pair nodes and inline misses the walks are short and uneven — +2.1 % (6596 -> 6734 Mrays/s; 24,2: 6740; 24,1: 6586; tools: RL_TUNE)
-      if (!g_sw.tune_set) P.tune[1] = 4;
+      if (!g_sw.tune_set) P.tune[1] = 4, P.tune[2] = 4;
       if (steal) rc = launch(rtiow_wave_kernel<NT, 4, false, true>, NT, rb, false);
 #ifdef RL_EXPERIMENTAL  // <.., 4, true> only under rl_debug_fast_stats (tools/sched.py): scheduler occupancy of the fast kernel; its box / sphere counts are its own
       else if (want_stats) rc = launch(rtiow_wave_kernel<NT, 4, true>, NT, rb, false);

@@ -642,7 +642,9 @@ __global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_kernel(RtiowPar
     }
     if ((n_trav | n_shade | n_fill | n_gen | n_leaf | n_shade2 | n_leaf2) == 0) break;
     uint32_t pick = ST_TRAV;
-    int best = n_trav;
+    // (A/B, RL_TUNE third field w: TRAV competes with n_trav * w / 4 — a TRAV step costs a tenth of a LEAF or SHADE block, so running it for
+    // fewer lanes feeds bigger LEAF / SHADE blocks; w = 4 is the plain most-lanes rule)
+    int best = LDS_SCENE == 4 ? (n_trav * (int)P.tune[2]) >> 2 : n_trav;
     if (n_leaf > best) pick = ST_LEAF, best = n_leaf;
     if (n_shade > best) pick = ST_SHADE, best = n_shade;
     if (n_fill > best) pick = ST_FILL, best = n_fill;
@@ -661,7 +663,7 @@ __global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_kernel(RtiowPar
     }
     if (pick == ST_TRAV) {
       // several steps per scheduling decision while the population stays near its starting size
-      int floor_n = (best * (int)P.tune[1]) >> 4;
+      int floor_n = ((LDS_SCENE == 4 ? n_trav : best) * (int)P.tune[1]) >> 4;
       auto trav_step = [&]() {
         if (STATS) {
           int np = __popcll(__ballot(state == ST_TRAV));
