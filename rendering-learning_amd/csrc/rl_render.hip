@@ -981,7 +981,7 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
     } else if (variant == 1031) {  // rings + the traversal stacks in LDS
       // four steps per scheduling round (a step is an Infinity Cache / L2 round trip here, not an LDS one: lanes that fall out of TRAV
       // should not wait 24 of them): cfg 5 +6.6 %, cfg 4 +0.7 % against the sphere kernel's 24
-      if (!g_sw.tune_set) P.tune[0] = 4, P.tune[3] = FASTG_STEP_BUDGET;
+      if (!g_sw.tune_set) P.tune[0] = 4, P.tune[2] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
       // The flavour with both the media code and the Perlin / acos / atan2 code spills 126 VGPRs at 256 registers.  For small frames (at most
       // one and a half pixels per lane of the 512-lane form: the frame's time is per-ray latency, and scratch round trips are part of it) it

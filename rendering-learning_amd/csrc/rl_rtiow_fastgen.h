@@ -290,14 +290,14 @@ __global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_fast_general_kernel(
     int n_leaf = __popcll(__ballot(state == ST_LEAF));
     if ((n_trav | n_shade | n_fill | n_gen | n_leaf) == 0) break;
     uint32_t pick = ST_TRAV;
-    int bestn = n_trav;
+    int bestn = (n_trav * (int)P.tune[2]) >> 2;  // (A/B, RL_TUNE third field: TRAV's weight against the other states in quarters; 4 = the plain most-lanes rule)
     if (n_leaf > bestn) pick = ST_LEAF, bestn = n_leaf;
     if (n_shade > bestn) pick = ST_SHADE, bestn = n_shade;
     if (n_fill > bestn) pick = ST_FILL, bestn = n_fill;
     if (n_gen > bestn) pick = ST_GEN, bestn = n_gen;
 
     if (pick == ST_TRAV) {
-      int floor_n = (bestn * (int)P.tune[1]) >> 4;
+      int floor_n = (n_trav * (int)P.tune[1]) >> 4;
       for (int it = 0; it < (int)P.tune[0]; it++) {
         if (state == ST_TRAV) {
 #ifdef RL_FASTG_VERIFY
