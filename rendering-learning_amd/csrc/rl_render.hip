@@ -49,6 +49,7 @@ struct Switches {
   double steal_max_fill = 3.0;   // RL_STEAL=<pixels per lane> (0 = off): work stealing on small shards
   bool fast_traversal = true;    // RL_FAST=0: counter-free renders use the reference-order kernels too
   unsigned fastg_top_max = 512;  // RL_FASTG_TOP=<n > 1>: at most n nodes
+  int rtc_blocks_per_cu = 0;     // RL_RTC_BLOCKS=<n>: workgroups per CU the RTC kernels are launched with (0 = as many as are resident at once: occupancy API)
   int fastg_nt256 = -1;          // RL_FASTG_NT256=0|1: never / always the one-wave-per-SIMD form of the fast general kernel (default: by frame size)
   bool fastg_top = true;         // RL_FASTG_TOP=0: the fast general kernel reads every node through L1 (A/B of the LDS tree top)
   bool tune_set = false;         // RL_TUNE="steps,floor16[,batch,fill]"
@@ -63,6 +64,7 @@ struct Switches {
   int thin_shift = 2;            // RL_THIN_SHIFT
   int wavefront = -1;            // RL_WAVEFRONT=1: general fast-traversal scenes in wavefront form (experimental library only)
   bool rtc_force_full = false;   // RL_RTC_FORCE_FULL
+  int rtc_regs = 256;            // RL_RTC_REGS=768|1024: rtc_kernel at the register budget of three / four waves per SIMD (experimental library only)
   int rtc_full_regs = 768;       // RL_RTC_FULL_REGS (256 / 512: experimental library only)
 } g_sw;
 unsigned long long g_last_slow_traces = 0;
@@ -90,6 +92,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_GENERAL_REGS")) w.general_regs = std::atoi(v);
   w.fastg512 = std::getenv("RL_FASTG512") != nullptr;
   if (const char *v = std::getenv("RL_FASTG_OCTO")) w.fastg_octo = std::atoi(v);
+  if (const char *v = std::getenv("RL_RTC_BLOCKS")) w.rtc_blocks_per_cu = std::max(0, std::atoi(v));
   if (const char *v = std::getenv("RL_FASTG_NT256")) w.fastg_nt256 = std::atoi(v) != 0;
   if (const char *v = std::getenv("RL_FASTG_TOP")) w.fastg_top = std::atoi(v) != 0, w.fastg_top_max = (unsigned)std::atoi(v) > 1u ? (unsigned)std::atoi(v) : 512u;
   if (const char *v = std::getenv("RL_GENERAL_NT")) w.general_nt = std::atoi(v);
@@ -98,6 +101,7 @@ void read_switches() {
   if (const char *v = std::getenv("RL_THIN_SHIFT")) w.thin_shift = std::min(6, std::max(1, std::atoi(v)));
   if (const char *v = std::getenv("RL_WAVEFRONT")) w.wavefront = std::atoi(v);
   w.rtc_force_full = std::getenv("RL_RTC_FORCE_FULL") != nullptr;
+  if (const char *v = std::getenv("RL_RTC_REGS")) w.rtc_regs = std::atoi(v);
   if (const char *v = std::getenv("RL_RTC_FULL_REGS")) w.rtc_full_regs = std::atoi(v);
   g_sw = w;
 #ifdef RL_EXPERIMENTAL
@@ -1686,7 +1690,28 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
   size_t lds = lds_scene ? scene_bytes : 0;
   uint64_t total = (uint64_t)W * nrows;
   uint64_t want = (total + NT - 1) / NT;
-  uint32_t blocks = (uint32_t)(want < (uint64_t)g_cus * 8 ? want : (uint64_t)g_cus * 8);
+  // The grid is exactly what is RESIDENT at once (occupancy API: 2 workgroups per CU for rtc_kernel's 241 VGPRs, 3 for rtc_full_kernel's budget):
+  // every workgroup stages the scene in LDS once and strides over the pixels.  Measured against the 8 per CU of rounds 1 - 2 (workgroups
+  // queueing behind the resident ones, each staging the scene again, the last round of them half empty): teapot AA 1 0.548 -> 0.317 ms per
+  // frame, AA 8 19.5 -> 17.0 ms; mirror scene 13.5 -> 10.8 ms, CSG scene 2.11 -> 1.76 ms.  RL_RTC_BLOCKS=<n> forces n per CU (A/B).
+  auto grid_for = [&](const void *kern, size_t dyn_lds) -> uint32_t {
+    uint64_t per_cu = (uint64_t)g_sw.rtc_blocks_per_cu;
+    if (per_cu == 0) {
+      static std::mutex mu;
+      static std::map<std::pair<const void *, size_t>, int> cache;
+      std::lock_guard<std::mutex> lk(mu);
+      auto key = std::make_pair(kern, dyn_lds ^ ((size_t)scene->device << 48));
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, dyn_lds) != hipSuccess || nb < 1) nb = 2;
+        it = cache.emplace(key, nb).first;
+      }
+      per_cu = (uint64_t)it->second;
+    }
+    return (uint32_t)(want < (uint64_t)g_cus * per_cu ? want : (uint64_t)g_cus * per_cu);
+  };
+  uint32_t blocks = 0;
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev0, stream));
   if (rc_.needs_full || g_sw.rtc_force_full) {  // (RL_RTC_FORCE_FULL: A/B, triangle-only worlds through the full kernel)  // shapes / CSG / patterns / reflection / refraction: the full World::color_at kernel
     RtcFullParams F{};
@@ -1697,15 +1722,31 @@ int rtc_render_launch(const rl_scene *scene, const rl_rtc_camera *cam, uint32_t 
     // run once per ray): measured 13.3 / 14.0 / 19.2 ms for 3 / 2 / 1 waves on the mirror scene at 1080p, 2.7 / 2.9 / 4.2 ms on the teapot
     // forced through this kernel.  RL_RTC_FULL_REGS=256|512 selects the other budgets (A/B).
 #ifdef RL_EXPERIMENTAL
-    if (g_sw.rtc_full_regs == 512) hipLaunchKernelGGL((rtc_full_kernel<NT, 512>), dim3(blocks), dim3(NT), 0, stream, F);
-    else if (g_sw.rtc_full_regs == 256) hipLaunchKernelGGL((rtc_full_kernel<NT, 256>), dim3(blocks), dim3(NT), 0, stream, F);
+    if (g_sw.rtc_full_regs == 512) { blocks = grid_for((const void *)rtc_full_kernel<NT, 512>, 0); hipLaunchKernelGGL((rtc_full_kernel<NT, 512>), dim3(blocks), dim3(NT), 0, stream, F); }
+    else if (g_sw.rtc_full_regs == 256) { blocks = grid_for((const void *)rtc_full_kernel<NT, 256>, 0); hipLaunchKernelGGL((rtc_full_kernel<NT, 256>), dim3(blocks), dim3(NT), 0, stream, F); }
     else
 #endif
+    {
+      blocks = grid_for((const void *)rtc_full_kernel<NT, 768>, 0);
       hipLaunchKernelGGL((rtc_full_kernel<NT, 768>), dim3(blocks), dim3(NT), 0, stream, F);
+    }
   // (241 VGPRs -> two waves per SIMD.  Measured in round 3 with the register budgets of three / four waves (68 / 128 spilled VGPRs): AA 8 19.5 -> 21.1 /
   // 22.5 ms, AA 1 0.547 -> 0.518 / 0.517 ms: the binary64 Moeller-Trumbore + Phong temporaries in scratch cost more than the extra waves hide.)
-  } else if (lds_scene) hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
-  else hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
+#ifdef RL_EXPERIMENTAL
+  } else if (lds_scene && g_sw.rtc_regs == 768) {
+    blocks = grid_for((const void *)rtc_kernel<NT, true, 768>, lds);
+    hipLaunchKernelGGL((rtc_kernel<NT, true, 768>), dim3(blocks), dim3(NT), lds, stream, P);
+  } else if (lds_scene && g_sw.rtc_regs == 1024) {
+    blocks = grid_for((const void *)rtc_kernel<NT, true, 1024>, lds);
+    hipLaunchKernelGGL((rtc_kernel<NT, true, 1024>), dim3(blocks), dim3(NT), lds, stream, P);
+#endif
+  } else if (lds_scene) {
+    blocks = grid_for((const void *)rtc_kernel<NT, true>, lds);
+    hipLaunchKernelGGL((rtc_kernel<NT, true>), dim3(blocks), dim3(NT), lds, stream, P);
+  } else {
+    blocks = grid_for((const void *)rtc_kernel<NT, false>, 0);
+    hipLaunchKernelGGL((rtc_kernel<NT, false>), dim3(blocks), dim3(NT), 0, stream, P);
+  }
   HIP_TRY(hipGetLastError());
   if (want_stats) HIP_TRY(hipEventRecord(scene->ev1, stream));
   return mark_render_end(scene, stream);

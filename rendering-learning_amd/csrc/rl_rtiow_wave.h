@@ -73,7 +73,7 @@ struct Ring {
   }
   __device__ __forceinline__ uint64_t next_u64() {
     uint32_t c = pos >> 4;
-    if (c - blk_lo >= nres) {  // rare inline path (long rejection streaks): always the rolled block function, a quarter of the code per call site
+    if (__builtin_expect(c - blk_lo >= nres, 0)) {  // rare inline path (long rejection streaks): always the rolled block function, a quarter of the code per call site
       const uint32_t nc = blk_lo + nres;
       chacha8_block_to_lds<NT, true>(key, nc, stream, s_rng + (size_t)(nc & 1u) * 8 * NT, tid);
       if (nres == 2) blk_lo++;
@@ -267,7 +267,7 @@ __device__ __forceinline__ bool fast_hit_is_order_sensitive(D3 oc, D3 d, double 
   float l2 = fmaf(ox, ox, fmaf(oy, oy, oz * oz));
   // eps |d_k| <= 64 * 1.8e-15 |oc|^2 / sqrt(disc) * max |d_k| (+ lower-order terms) must stay below 5e-5 r
   bool quiet = 2.4e-13f * l2 * dmax < 5e-5f * r32 * sq32 && qm < 0.9999f * r32 && sq32 > 1e-3f * dmax * r32;
-  if (quiet) return false;
+  if (__builtin_expect(quiet, 1)) return false;
   D3 q = oc + d * t;
   double eps = fast_root_error(len2(oc), sq, r_l, r_u, oimax);
   bool grazing = sq <= 1e-6 * fabs(half_b);
@@ -745,7 +745,7 @@ __global__ void RL_KERNEL_ALIGN __launch_bounds__(NT) rtiow_wave_kernel(RtiowPar
     } else if (pick == ST_LEAF) {
       if (LDS_SCENE == 4) {
         if (state == ST_LEAF) {
-          if (pc == FAST_SLOW) {  // rare: the answer may depend on the visiting order -> the reference's own fold
+          if (__builtin_expect(pc == FAST_SLOW, 0)) {  // rare: the answer may depend on the visiting order -> the reference's own fold
             c_flag += fast_slow_trace(P.ops, spheres, o, d, time, closest, hit_prim);
             c_slow++;
             state = shade_state();
