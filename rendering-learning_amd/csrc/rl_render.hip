@@ -1423,6 +1423,7 @@ void rl_debug_set_lpt(int on) { g_sw.lpt = on != 0; }
 void rl_debug_set_coop(int on) { g_sw.coop_small = on != 0; }
 void rl_debug_set_steal(double max_fill) { g_sw.steal_max_fill = max_fill; }
 void rl_debug_set_fast_traversal(int on) { g_sw.fast_traversal = on != 0; }
+void rl_debug_set_rtc_blocks(int per_cu) { g_sw.rtc_blocks_per_cu = per_cu < 0 ? 0 : per_cu; }  // 0: as many as are resident (default); n: n per CU (tests)
 void rl_debug_set_fastg_one_wave(int mode) { g_sw.fastg_nt256 = mode; }  // -1: by frame size (default), 0 / 1: never / always the one-wave-per-SIMD form (tests)
 void rl_debug_fast_stats(int on) {  // the instrumented fast kernel <1024, 4, true> exists in the experimental library only
 #ifdef RL_EXPERIMENTAL

@@ -138,6 +138,22 @@ def test_rtc_teapot_antialiased_and_sharded(rl, oracle, golden):
     assert np.abs(img - cpu).max() <= 1e-12
     for g in range(4):
         assert np.array_equal(world.render(3, row_first=g, row_step=4), img[g::4])
+    # the grid is the number of workgroups resident at once (occupancy API); any other count strides over the same pixels: same frame, same counters
+    L = rl.api.render_lib()
+    L.rl_debug_set_rtc_blocks.argtypes = [rl.api.C.c_int]
+    ref_stats = {}
+    world.render(3, stats=ref_stats)
+    mirror = rl.RtcWorld.test_mirror_scene(120, 80)  # the full World::color_at kernel
+    mref = mirror.render(1)
+    try:
+        for per_cu in (1, 3, 8, 64):
+            L.rl_debug_set_rtc_blocks(per_cu)
+            st = {}
+            assert np.array_equal(world.render(3, stats=st), img), per_cu
+            assert all(st[k] == ref_stats[k] for k in ("rays", "node_tests", "planar_tests", "instance_enters", "flagged")), per_cu
+            assert np.array_equal(mirror.render(1), mref), per_cu
+    finally:
+        L.rl_debug_set_rtc_blocks(0)
 
 
 def test_rtiow_cost_sorted_two_phase_render_is_bit_identical(rl, oracle):
