@@ -988,12 +988,13 @@ int rtiow_render_launch(const rl_scene *scene, const rl_rtiow_camera *cam, uint6
       if (!g_sw.tune_set) P.tune[0] = 4, P.tune[2] = 4, P.tune[3] = FASTG_STEP_BUDGET;
       bool trans = rt.has_noise || rt.has_sphere_uv;
       // The flavour with both the media code and the Perlin / acos / atan2 code spills 126 VGPRs at 256 registers.  For small frames (at most
-      // one and a half pixels per lane of the 512-lane form: the frame's time is per-ray latency, and scratch round trips are part of it) it
-      // runs as ONE wave per SIMD with the 512-register budget instead (what would spill lives in AGPRs): final_scene.rs (400x400) 442 ->
-      // 494 ... 513 Mrays/s.  Measured and not taken: the same for the other flavours (quads.rs -17 %, flat_world.rs -24 %, cornell_smoke.rs at
+      // three pixels per lane of the 512-lane form: the frame's time is per-ray latency, and scratch round trips are part of it) it
+      // runs as ONE wave per SIMD with the 512-register budget instead (what would spill lives in AGPRs): final_scene.rs at 400x400 442 ->
+      // 522 Mrays/s, at 560x560 664 -> 782, at 640x640 786 -> 811; from 720x720 on the two-wave form wins (975 against 818; 1100 against 810
+      // at 1000x1000: the one-wave form's throughput ends at ~810 Mrays/s).  Measured and not taken: the same for the other flavours (quads.rs -17 %, flat_world.rs -24 %, cornell_smoke.rs at
       // 600x600 -30 %: they spill little, and lose the second wave's latency hiding).  RL_FASTG_NT256=1 / 0 forces it on / off (A/B).
       const bool media = H.fg.stage_roots.size() > 1;
-      const bool one_wave = trans && media && (g_sw.fastg_nt256 >= 0 ? g_sw.fastg_nt256 != 0 : (uint64_t)nrows * W <= (uint64_t)g_cus * 768u);
+      const bool one_wave = trans && media && (g_sw.fastg_nt256 >= 0 ? g_sw.fastg_nt256 != 0 : (uint64_t)nrows * W <= (uint64_t)g_cus * 1536u);
       if (one_wave) {
         constexpr int NT = 256, SD = 40;
         size_t rb = fastg_lds(NT, SD);
